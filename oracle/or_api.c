@@ -1,0 +1,47 @@
+/* or_api.c - whole env step over a batch (TEST INFRASTRUCTURE; see oracle.h).
+ * One env step = main.py:119-129 (TSID tick) then main.py:192-195 (base teleport, ctrl map,
+ * mj_step).  OpenMP over envs is used only by bench.py's cpu_baseline leg. */
+#include "oracle.h"
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+int or_env_step_batch(const OrModel *m, const double *params, int n, double *q, double *v, double *qpos,
+                      double *qvel, double *qacc_ws, const double *com_ref, const double *posture_ref,
+                      const double *foot_ref, const double *contact_ref, const uint8_t *contact_active,
+                      const double *cop_frames, double *tau, double *dv, double *f, int32_t *status,
+                      double *obs, int32_t *ncon, int32_t *con_geom, int nthreads) {
+  const int sim = params[P_SIM_ENABLED] != 0.0;
+  const int quirks = params[P_QUIRKS] != 0.0;
+#ifdef _OPENMP
+  if (nthreads > 0) omp_set_num_threads(nthreads);
+#pragma omp parallel for schedule(dynamic, 4)
+#endif
+  for (int e = 0; e < n; e++) {
+    double *qe = q + (size_t)e * OR_NQ, *ve = v + (size_t)e * OR_NV;
+    int st = or_tsid_tick(m, params, qe, ve, com_ref + (size_t)e * 9, posture_ref + (size_t)e * OR_NA,
+                          foot_ref + (size_t)e * 48, contact_ref + (size_t)e * 24, contact_active + (size_t)e * 2,
+                          cop_frames ? cop_frames + (size_t)e * 24 : NULL, tau + (size_t)e * OR_NA,
+                          dv + (size_t)e * OR_NV, f + (size_t)e * 24, obs ? obs + (size_t)e * OR_NOBS : NULL, NULL);
+    status[e] = st;
+    if (!sim) continue;
+    double *qp = qpos + (size_t)e * OR_NQ, *qv = qvel + (size_t)e * OR_NV;
+    double ctrl[OR_NA];
+    /* main.py:192  mj_data.qpos[:7] = q[:7]  (quirk F6a: xyzw copied into the wxyz slot) */
+    for (int i = 0; i < 3; i++) qp[i] = qe[i];
+    if (quirks) for (int i = 0; i < 4; i++) qp[3 + i] = qe[3 + i];
+    else { qp[3] = qe[6]; qp[4] = qe[3]; qp[5] = qe[4]; qp[6] = qe[5]; }
+    /* main.py:193-194  ctrl = map_tsid_to_mujoco(q) */
+    for (int a = 0; a < OR_NA; a++) ctrl[a] = qe[m->mj_ctrl_qidx[a]];
+    OrSimInfo info;
+    int rc = or_sim_step(m, qp, qv, ctrl, qacc_ws + (size_t)e * OR_NV, &info);
+    if (rc) status[e] |= 0x100;
+    if (ncon) ncon[e] = info.ncon;
+    if (con_geom) {
+      for (int c = 0; c < OR_MAXCON; c++)
+        con_geom[(size_t)e * OR_MAXCON + c] = c < info.ncon ? (info.con_geom[c] << 16 | info.con_vert[c]) : -1;
+    }
+  }
+  return 0;
+}

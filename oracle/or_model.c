@@ -1,0 +1,96 @@
+/* or_model.c - blob parser for the oracle (TEST INFRASTRUCTURE; see oracle.h).
+ * Blob layout: tsid_control_amd/model_compiler.py, include/tsidb_model.h. */
+#include "oracle.h"
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef struct {
+  char name[24];
+  uint32_t dtype, count;
+  uint64_t offset;
+} Sect;
+
+static const Sect *find(const uint8_t *b, const char *name) {
+  uint32_t n;
+  memcpy(&n, b + 8, 4);
+  const Sect *s = (const Sect *)(b + 16);
+  for (uint32_t i = 0; i < n; i++)
+    if (strncmp(s[i].name, name, 24) == 0) return &s[i];
+  fprintf(stderr, "oracle: blob section %s missing\n", name);
+  return NULL;
+}
+
+static int getf(const uint8_t *b, const char *name, double *dst, uint32_t cnt) {
+  const Sect *s = find(b, name);
+  if (!s || s->dtype != 0 || s->count != cnt) {
+    fprintf(stderr, "oracle: section %s bad (count %u want %u)\n", name, s ? s->count : 0, cnt);
+    return -1;
+  }
+  memcpy(dst, b + s->offset, cnt * sizeof(double));
+  return 0;
+}
+static int geti(const uint8_t *b, const char *name, int *dst, uint32_t cnt) {
+  const Sect *s = find(b, name);
+  if (!s || s->dtype != 1 || s->count != cnt) {
+    fprintf(stderr, "oracle: section %s bad\n", name);
+    return -1;
+  }
+  memcpy(dst, b + s->offset, cnt * sizeof(int));
+  return 0;
+}
+
+OrModel *or_model_load(const void *blob, size_t nbytes) {
+  if (nbytes < 16 || memcmp(blob, "TSIDBM01", 8) != 0) return NULL;
+  uint8_t *b = (uint8_t *)malloc(nbytes);
+  memcpy(b, blob, nbytes);
+  OrModel *m = (OrModel *)calloc(1, sizeof(OrModel));
+  m->owned = b;
+  int e = 0;
+  e |= geti(b, "pin_parent", m->pin_parent, OR_NJ);
+  e |= getf(b, "pin_place", &m->pin_place[0][0], OR_NJ * 12);
+  e |= getf(b, "pin_inertia", &m->pin_inertia[0][0], OR_NJ * 10);
+  e |= geti(b, "pin_frame_parent", m->frame_parent, OR_NF);
+  e |= getf(b, "pin_frame_place", &m->frame_place[0][0], OR_NF * 12);
+  e |= getf(b, "pin_effort", m->effort, OR_NA);
+  e |= getf(b, "pin_velocity", m->velocity, OR_NA);
+  e |= getf(b, "pin_q0", m->q0, OR_NQ);
+  e |= geti(b, "mj_parent", m->mj_parent, OR_NB);
+  e |= getf(b, "mj_pos", &m->mj_pos[0][0], OR_NB * 3);
+  e |= getf(b, "mj_quat", &m->mj_quat[0][0], OR_NB * 4);
+  e |= getf(b, "mj_inertia", &m->mj_inertia[0][0], OR_NB * 10);
+  e |= getf(b, "mj_armature", m->mj_armature, OR_NV);
+  e |= getf(b, "mj_frictionloss", m->mj_frictionloss, OR_NV);
+  e |= getf(b, "mj_dof_M0", m->mj_dof_M0, OR_NV);
+  e |= getf(b, "mj_dof_invw0", m->mj_dof_invw0, OR_NV);
+  e |= getf(b, "mj_body_invw0", &m->mj_body_invw0[0][0], OR_NB * 2);
+  e |= geti(b, "mj_act_dof", m->mj_act_dof, OR_NA);
+  e |= getf(b, "mj_act_kp", m->mj_act_kp, OR_NA);
+  e |= getf(b, "mj_act_kv", m->mj_act_kv, OR_NA);
+  e |= geti(b, "mj_ctrl_qidx", m->mj_ctrl_qidx, OR_NA);
+  e |= geti(b, "mj_hull_adr", m->hull_adr, OR_NB + 1);
+  e |= getf(b, "mj_rbound", &m->rbound[0][0], OR_NB * 4);
+  e |= getf(b, "mj_opt", m->opt, 7);
+  e |= getf(b, "mj_contact", m->contact, 8);
+  const Sect *hv = find(b, "mj_hull_vert"), *ea = find(b, "mj_hull_eadr"), *ed = find(b, "mj_hull_edge");
+  if (e || !hv || !ea || !ed) {
+    or_model_free(m);
+    return NULL;
+  }
+  m->nhullvert = (int)(hv->count / 3);
+  m->nhulledge = (int)ed->count;
+  m->hull_vert = (const double *)(b + hv->offset);
+  m->hull_eadr = (const int *)(b + ea->offset);
+  m->hull_edge = (const int *)(b + ed->offset);
+  /* MuJoCo stat.meaninertia: mean diagonal of M at qpos0 */
+  double s = 0;
+  for (int i = 0; i < OR_NV; i++) s += m->mj_dof_M0[i];
+  m->meaninertia = s / OR_NV;
+  return m;
+}
+
+void or_model_free(OrModel *m) {
+  if (!m) return;
+  free(m->owned);
+  free(m);
+}

@@ -1,0 +1,130 @@
+/* oracle.h - CPU float64 restatement of the reference hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
+ * The product (tsid_control_amd/, libtsidb.so) never links, imports or calls it.
+ *
+ * PARITY UNPINNED for the native stages: the reference's arithmetic lives in tsid, pinocchio,
+ * eiquadprog and mujoco (none vendored, pinned or installed) and the reference holds
+ * no tests or golden vectors.  Each function below restates the published algorithm of the library
+ * the cited reference call site reaches, and is pinned only by the invariants in tests/
+ * (CRBA == RNEA columns, KKT residuals, Newton-Euler balance, closed-form sim cases).
+ */
+#ifndef TSIDB_ORACLE_H
+#define TSIDB_ORACLE_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { OR_NJ = 21, OR_NQ = 27, OR_NV = 26, OR_NA = 20, OR_NB = 21, OR_NF = 2 };
+enum { OR_NVAR = 50, OR_NEQ = 18, OR_NIN = 160 };
+enum { OR_MAXCON = 32, OR_MAXEFC = 20 + 4 * OR_MAXCON, OR_NOBS = 65 };
+
+/* parameter vector indices (RobotConfig values; ctrl/conf.py:21-72) */
+enum {
+  P_DT = 0, P_MU, P_FMIN, P_FMAX, P_W_FORCEREF, P_KP_CONTACT, P_KD_CONTACT,
+  P_W_FOOT, P_KP_FOOT, P_KD_FOOT, P_W_COM, P_KP_COM, P_KD_COM, P_W_POSTURE,
+  P_HESS_REG, P_QUIRKS, P_NORMAL /*3*/, P_CPOINTS = P_NORMAL + 3 /*12*/,
+  P_KP_POSTURE = P_CPOINTS + 12 /*20*/, P_KD_POSTURE = P_KP_POSTURE + 20,
+  P_TAU_MAX = P_KD_POSTURE + 20, P_V_MAX = P_TAU_MAX + 20, P_MAX_ITER = P_V_MAX + 20,
+  P_SIM_ENABLED, P_COUNT = 128
+};
+
+typedef struct {
+  /* TSID side (pinocchio conventions) */
+  int pin_parent[OR_NJ];
+  double pin_place[OR_NJ][12];   /* R row-major (9), p (3): joint frame in parent joint frame */
+  double pin_inertia[OR_NJ][10]; /* mass, com(3), Ixx Ixy Ixz Iyy Iyz Izz about com */
+  int frame_parent[OR_NF];
+  double frame_place[OR_NF][12];
+  double effort[OR_NA], velocity[OR_NA], q0[OR_NQ];
+  /* sim side (MuJoCo conventions) */
+  int mj_parent[OR_NB];
+  double mj_pos[OR_NB][3], mj_quat[OR_NB][4], mj_inertia[OR_NB][10];
+  double mj_armature[OR_NV], mj_frictionloss[OR_NV], mj_dof_M0[OR_NV], mj_dof_invw0[OR_NV];
+  double mj_body_invw0[OR_NB][2];
+  int mj_act_dof[OR_NA];
+  double mj_act_kp[OR_NA], mj_act_kv[OR_NA];
+  int mj_ctrl_qidx[OR_NA];
+  int hull_adr[OR_NB + 1];
+  int nhullvert, nhulledge;
+  const double *hull_vert; /* [nhullvert][3], body frame */
+  const int *hull_eadr;    /* [nhullvert+1] */
+  const int *hull_edge;    /* neighbour ids local to the body's hull */
+  double rbound[OR_NB][4];
+  double opt[7];     /* dt gz tol iters ls_iters ls_tol impratio */
+  double contact[8]; /* mu solref[2] solimp[5] */
+  double meaninertia;
+  void *owned;
+} OrModel;
+
+typedef struct {
+  double M[OR_NV][OR_NV], h[OR_NV];
+  double com[3], vcom[3], acom[3], Jcom[3][OR_NV];
+  double oMf[OR_NF][12];          /* frame placement R(9) p(3) */
+  double Jf[OR_NF][6][OR_NV];     /* frame Jacobian, LOCAL */
+  double vf[OR_NF][6], af[OR_NF][6]; /* frame velocity, classical drift acceleration (LOCAL) */
+  double mass;
+} OrTerms;
+
+typedef struct {
+  int nvar, neq, nin; /* nin = one-sided rows */
+  double H[OR_NVAR][OR_NVAR], g[OR_NVAR];
+  double CE[OR_NEQ][OR_NVAR], ce0[OR_NEQ];
+  double CI[OR_NIN][OR_NVAR], ci0[OR_NIN];
+  int slot_foot[OR_NF]; /* force slot -> foot id, -1 if unused */
+} OrQP;
+
+typedef struct {
+  double x[OR_NVAR], u[OR_NEQ + OR_NIN];
+  int A[OR_NEQ + OR_NIN], iq, iter, status;
+  double f_value;
+} OrQPSol;
+
+OrModel *or_model_load(const void *blob, size_t nbytes);
+void or_model_free(OrModel *m);
+
+/* pinocchio-side terms: what tsid::RobotWrapper::computeAllTerms leaves in Data (main.py:119) */
+void or_rbd_terms(const OrModel *m, const double *q, const double *v, OrTerms *t);
+void or_rnea(const OrModel *m, const double *q, const double *v, const double *a, double *tau);
+void or_integrate(const double *q, const double *vdt, double *qout); /* pin.integrate, WalkController.py:294 */
+void or_log6(const double *Mrel12, double *out6);
+
+/* TSID problem (formulation.computeProblemData + SolverHQuadProgFast data copy; main.py:119-121) */
+void or_tsid_assemble(const OrModel *m, const double *params, const OrTerms *t, const double *q,
+                      const double *v, const double *com_ref, const double *posture_ref,
+                      const double *foot_ref, const double *contact_ref, const uint8_t *contact_active,
+                      OrQP *qp);
+int or_qp_solve(const OrQP *qp, int max_iter, OrQPSol *sol); /* eiquadprog-fast restatement */
+
+/* one TSID tick for one env: main.py:119-129,132-142 */
+int or_tsid_tick(const OrModel *m, const double *params, double *q, double *v, const double *com_ref,
+                 const double *posture_ref, const double *foot_ref, const double *contact_ref,
+                 const uint8_t *contact_active, const double *cop_frames /*2x12, quirk (e)*/,
+                 double *tau, double *dv, double *f, double *obs, int *iters);
+
+/* MuJoCo-subset step for one env: main.py:195 */
+typedef struct {
+  int ncon, nefc, solver_iter;
+  int con_geom[OR_MAXCON]; /* body index of the mesh geom (geom1 is always the floor plane) */
+  int con_vert[OR_MAXCON];
+  double con_dist[OR_MAXCON], con_pos[OR_MAXCON][3];
+  double efc_force[OR_MAXEFC];
+  double qacc[OR_NV], qacc_smooth[OR_NV], qfrc_bias[OR_NV], qfrc_actuator[OR_NV], M[OR_NV][OR_NV];
+} OrSimInfo;
+int or_sim_step(const OrModel *m, double *qpos, double *qvel, const double *ctrl, double *qacc_ws,
+                OrSimInfo *info);
+
+/* whole env step (tick + base teleport + ctrl map + sim step): main.py:119-129,192-195 */
+int or_env_step_batch(const OrModel *m, const double *params, int n, double *q, double *v, double *qpos,
+                      double *qvel, double *qacc_ws, const double *com_ref, const double *posture_ref,
+                      const double *foot_ref, const double *contact_ref, const uint8_t *contact_active,
+                      const double *cop_frames, double *tau, double *dv, double *f, int32_t *status,
+                      double *obs, int32_t *ncon, int32_t *con_geom, int nthreads);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

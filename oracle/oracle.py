@@ -1,0 +1,176 @@
+"""ctypes binding of the CPU float64 oracle (oracle/liboracle.so).  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module; the product
+package (tsid_control_amd/) never does.  PARITY UNPINNED for the native stages - see oracle.h.
+"""
+import ctypes as C
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+HERE = Path(__file__).parent
+NQ, NV, NA, NVAR, NEQ, NIN, MAXCON, MAXEFC, NOBS = 27, 26, 20, 50, 18, 160, 32, 20 + 4 * 32, 65
+
+
+class OrTerms(C.Structure):
+    _fields_ = [("M", C.c_double * (NV * NV)), ("h", C.c_double * NV), ("com", C.c_double * 3),
+                ("vcom", C.c_double * 3), ("acom", C.c_double * 3), ("Jcom", C.c_double * (3 * NV)),
+                ("oMf", C.c_double * 24), ("Jf", C.c_double * (2 * 6 * NV)), ("vf", C.c_double * 12),
+                ("af", C.c_double * 12), ("mass", C.c_double)]
+
+
+class OrQP(C.Structure):
+    _fields_ = [("nvar", C.c_int), ("neq", C.c_int), ("nin", C.c_int),
+                ("H", C.c_double * (NVAR * NVAR)), ("g", C.c_double * NVAR),
+                ("CE", C.c_double * (NEQ * NVAR)), ("ce0", C.c_double * NEQ),
+                ("CI", C.c_double * (NIN * NVAR)), ("ci0", C.c_double * NIN), ("slot_foot", C.c_int * 2)]
+
+
+class OrQPSol(C.Structure):
+    _fields_ = [("x", C.c_double * NVAR), ("u", C.c_double * (NEQ + NIN)), ("A", C.c_int * (NEQ + NIN)),
+                ("iq", C.c_int), ("iter", C.c_int), ("status", C.c_int), ("f_value", C.c_double)]
+
+
+class OrSimInfo(C.Structure):
+    _fields_ = [("ncon", C.c_int), ("nefc", C.c_int), ("solver_iter", C.c_int),
+                ("con_geom", C.c_int * MAXCON), ("con_vert", C.c_int * MAXCON),
+                ("con_dist", C.c_double * MAXCON), ("con_pos", C.c_double * (3 * MAXCON)),
+                ("efc_force", C.c_double * MAXEFC), ("qacc", C.c_double * NV), ("qacc_smooth", C.c_double * NV),
+                ("qfrc_bias", C.c_double * NV), ("qfrc_actuator", C.c_double * NV), ("M", C.c_double * (NV * NV))]
+
+
+def build(force=False):
+    so = HERE / "liboracle.so"
+    srcs = list(HERE.glob("*.c")) + [HERE / "oracle.h"]
+    if force or not so.exists() or any(s.stat().st_mtime > so.stat().st_mtime for s in srcs):
+        subprocess.run(["make", "-C", str(HERE), "liboracle.so"], check=True, capture_output=True)
+    return so
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+class Oracle:
+    def __init__(self, blob_bytes: bytes, lib_path=None):
+        so = Path(lib_path) if lib_path else HERE / "liboracle.so"
+        if not so.exists():
+            so = build()
+        self.lib = L = C.CDLL(str(so))
+        L.or_model_load.restype = C.c_void_p
+        L.or_model_load.argtypes = [C.c_char_p, C.c_size_t]
+        for name in ("or_model_free", "or_rbd_terms", "or_rnea", "or_integrate", "or_log6", "or_tsid_assemble"):
+            getattr(L, name).restype = None
+        for name in ("or_qp_solve", "or_tsid_tick", "or_sim_step", "or_env_step_batch"):
+            getattr(L, name).restype = C.c_int
+        self.m = C.c_void_p(L.or_model_load(blob_bytes, len(blob_bytes)))
+        if not self.m:
+            raise RuntimeError("oracle: model blob rejected")
+
+    def __del__(self):
+        try:
+            self.lib.or_model_free(self.m)
+        except Exception:
+            pass
+
+    # ---- rigid-body terms
+    def terms(self, q, v):
+        t = OrTerms()
+        q, v = _f64(q), _f64(v)
+        self.lib.or_rbd_terms(self.m, _p(q), _p(v), C.byref(t))
+        g = lambda f, *s: np.array(f, dtype=np.float64).reshape(*s)
+        return dict(M=g(t.M, NV, NV), h=g(t.h, NV), com=g(t.com, 3), vcom=g(t.vcom, 3), acom=g(t.acom, 3),
+                    Jcom=g(t.Jcom, 3, NV), oMf=g(t.oMf, 2, 12), Jf=g(t.Jf, 2, 6, NV), vf=g(t.vf, 2, 6),
+                    af=g(t.af, 2, 6), mass=t.mass, _raw=t)
+
+    def rnea(self, q, v, a):
+        q, v, a = _f64(q), _f64(v), _f64(a)
+        tau = np.zeros(NV)
+        self.lib.or_rnea(self.m, _p(q), _p(v), _p(a), _p(tau))
+        return tau
+
+    def integrate(self, q, vdt):
+        q, vdt = _f64(q), _f64(vdt)
+        out = np.zeros(NQ)
+        self.lib.or_integrate(_p(q), _p(vdt), _p(out))
+        return out
+
+    def log6(self, R, p):
+        m = _f64(np.concatenate([np.asarray(R).reshape(-1), np.asarray(p).reshape(-1)]))
+        out = np.zeros(6)
+        self.lib.or_log6(_p(m), _p(out))
+        return out
+
+    # ---- TSID problem
+    def assemble(self, params, q, v, com_ref, posture_ref, foot_ref, contact_ref, contact_active):
+        t = self.terms(q, v)["_raw"]
+        qp = OrQP()
+        a = [_f64(x) for x in (params, q, v, com_ref, posture_ref, foot_ref, contact_ref)]
+        ca = np.ascontiguousarray(contact_active, dtype=np.uint8)
+        self.lib.or_tsid_assemble(self.m, _p(a[0]), C.byref(t), _p(a[1]), _p(a[2]), _p(a[3]), _p(a[4]), _p(a[5]),
+                                  _p(a[6]), _p(ca), C.byref(qp))
+        n, ne, ni = qp.nvar, qp.neq, qp.nin
+        H = np.array(qp.H).reshape(NVAR, NVAR)[:n, :n]
+        CE = np.array(qp.CE).reshape(NEQ, NVAR)[:ne, :n]
+        CI = np.array(qp.CI).reshape(NIN, NVAR)[:ni, :n]
+        return dict(H=H, g=np.array(qp.g)[:n], CE=CE, ce0=np.array(qp.ce0)[:ne], CI=CI, ci0=np.array(qp.ci0)[:ni],
+                    slot_foot=list(qp.slot_foot), _raw=qp)
+
+    def qp_solve(self, qp_raw, max_iter=1000):
+        sol = OrQPSol()
+        st = self.lib.or_qp_solve(C.byref(qp_raw), max_iter, C.byref(sol))
+        n = qp_raw.nvar
+        return dict(status=st, x=np.array(sol.x)[:n], u=np.array(sol.u)[:sol.iq], A=np.array(sol.A)[:sol.iq],
+                    iq=sol.iq, iter=sol.iter, f_value=sol.f_value)
+
+    def tsid_tick(self, params, q, v, com_ref, posture_ref, foot_ref, contact_ref, contact_active, cop_frames=None):
+        """In-place on q, v (float64 arrays). Returns dict(tau, dv, f, obs, status, iters)."""
+        assert q.dtype == np.float64 and v.dtype == np.float64
+        a = [_f64(x) for x in (params, com_ref, posture_ref, foot_ref, contact_ref)]
+        ca = np.ascontiguousarray(contact_active, dtype=np.uint8)
+        cf = _f64(cop_frames) if cop_frames is not None else None
+        tau, dv, f, obs = np.zeros(NA), np.zeros(NV), np.zeros(24), np.zeros(NOBS)
+        it = C.c_int(0)
+        st = self.lib.or_tsid_tick(self.m, _p(a[0]), _p(q), _p(v), _p(a[1]), _p(a[2]), _p(a[3]), _p(a[4]), _p(ca),
+                                   _p(cf) if cf is not None else None, _p(tau), _p(dv), _p(f), _p(obs), C.byref(it))
+        return dict(tau=tau, dv=dv, f=f, obs=obs, status=st, iters=it.value)
+
+    # ---- sim
+    def sim_step(self, qpos, qvel, ctrl, qacc_ws):
+        assert all(x.dtype == np.float64 for x in (qpos, qvel, qacc_ws))
+        ctrl = _f64(ctrl)
+        info = OrSimInfo()
+        rc = self.lib.or_sim_step(self.m, _p(qpos), _p(qvel), _p(ctrl), _p(qacc_ws), C.byref(info))
+        nc, ne = info.ncon, info.nefc
+        return dict(rc=rc, ncon=nc, nefc=ne, iters=info.solver_iter, con_geom=np.array(info.con_geom)[:nc],
+                    con_vert=np.array(info.con_vert)[:nc], con_dist=np.array(info.con_dist)[:nc],
+                    con_pos=np.array(info.con_pos).reshape(MAXCON, 3)[:nc], efc_force=np.array(info.efc_force)[:ne],
+                    qacc=np.array(info.qacc), qacc_smooth=np.array(info.qacc_smooth),
+                    qfrc_bias=np.array(info.qfrc_bias), qfrc_actuator=np.array(info.qfrc_actuator),
+                    M=np.array(info.M).reshape(NV, NV))
+
+    # ---- batch env step (all arrays float64, env-major, updated in place)
+    def env_step_batch(self, params, st, nthreads=1):
+        n = st["q"].shape[0]
+        params = _f64(params)
+        cf = st.get("cop_frames")
+        self.lib.or_env_step_batch(
+            self.m, _p(params), n, _p(st["q"]), _p(st["v"]), _p(st["qpos"]), _p(st["qvel"]), _p(st["qacc_ws"]),
+            _p(st["com_ref"]), _p(st["posture_ref"]), _p(st["foot_ref"]), _p(st["contact_ref"]),
+            _p(st["contact_active"]), _p(cf) if cf is not None else None, _p(st["tau"]), _p(st["dv"]), _p(st["f"]),
+            _p(st["status"]), _p(st["obs"]), _p(st["ncon"]), _p(st["con_geom"]), int(nthreads))
+
+
+def new_state(n):
+    """Zeroed env-major float64 state/IO arrays in the layout or_env_step_batch expects."""
+    z = lambda *s: np.zeros(s, dtype=np.float64)
+    return dict(q=z(n, NQ), v=z(n, NV), qpos=z(n, NQ), qvel=z(n, NV), qacc_ws=z(n, NV), com_ref=z(n, 9),
+                posture_ref=z(n, NA), foot_ref=z(n, 2, 24), contact_ref=z(n, 2, 12),
+                contact_active=np.ones((n, 2), dtype=np.uint8), cop_frames=z(n, 2, 12), tau=z(n, NA), dv=z(n, NV),
+                f=z(n, 24), status=np.zeros(n, dtype=np.int32), obs=z(n, NOBS), ncon=np.zeros(n, dtype=np.int32),
+                con_geom=np.zeros((n, MAXCON), dtype=np.int32))

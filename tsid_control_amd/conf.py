@@ -1,0 +1,90 @@
+"""RobotConfig - attribute-for-attribute mirror of the reference's ctrl/conf.py:5-75.
+
+Every attribute name and value of the reference class is kept; the reference's
+`import pinocchio` (conf.py:2-3) is dropped because nothing here needs it.  Batch-only knobs are
+added at the bottom without renaming anything.
+"""
+import numpy as np
+
+
+class RobotConfig:
+    """Configuration parameters for the robot controller (ctrl/conf.py:5-75)."""
+
+    # Robot configuration (conf.py:9-18).  The asset files themselves do not travel; the compiled
+    # model blob below stands for robot_mod.urdf + robot.srdf + scene.xml.
+    robot_path = "./robot/v1"
+    root_urdf = f"{robot_path}/urdf"
+    urdf = f"{robot_path}/urdf/robot_mod.urdf"
+    pin_urdf = f"{root_urdf}/robot_mod.urdf"
+    mjcf = f"{robot_path}/mujoco/scene.xml"
+    srdf = f"{root_urdf}/robot.srdf"
+
+    lf_fixed_joint = "left_sole_joint_fixed"
+    rf_fixed_joint = "right_sole_joint_fixed"
+
+    # Controller settings (conf.py:21)
+    dt = 0.002
+
+    # Step parameters (conf.py:24-28)
+    step_height = 0.2
+    step_width = 0.2
+    step_length = 0.3
+    step_duration = 0.5
+    rise_ratio = 0.5
+
+    # Frame dimensions (conf.py:31-35)
+    lxn = 0.055
+    lyn = 0.0275
+    lxp = 0.055
+    lyp = 0.0275
+    lz = 0.0
+
+    # Contact parameters (conf.py:38-44)
+    mu = 0.5
+    fMin = 10.0
+    fMax = 1000.0
+    contactNormal = np.array([0.0, 0.0, 1.0])
+    w_contact = -1.0
+    w_forceRef = 1e-5
+    kp_contact = 10.0
+
+    # Foot trajectory parameters (conf.py:47-48)
+    w_foot = 1e-1
+    kp_foot = 10.0
+
+    # CoM parameters (conf.py:51-52)
+    w_com = 1e-1
+    kp_com = 10.0
+
+    # Posture parameters (conf.py:55-63)
+    w_posture = 1e-1
+    kp_posture = 10.0
+    gain_vector = np.array([
+        100.0, 100.0,  # head
+        10.0, 5.0, 5.0, 1.0, 1.0, 1.0,  # left leg
+        10.0, 10.0, 10.0,  # left arm
+        10.0, 5.0, 5.0, 1.0, 1.0, 1.0,  # right leg
+        10.0, 10.0, 10.0,  # right arm
+    ])
+
+    # Masks for posture task (conf.py:66)
+    masks_posture = np.ones(20)
+
+    # Joint limit parameters (conf.py:69-72)
+    tau_max_scaling = 5.0
+    v_max_scaling = 10.0
+    w_torque_bounds = 1e-2
+    w_joint_bounds = 1e-2
+
+    # conf.py:74-75
+    visualizer = None
+
+    # ---- batch-only additions (no reference counterpart)
+    model_blob = None          # path to a compiled model blob; None -> packaged assets/op3_v1.tsidb
+    num_envs = 1
+    device = "cuda"
+    dtype = "f64"              # arithmetic type of the HIP path: "f64" (reference precision) or "f32"
+    reference_quirks = True    # reproduce SURVEY.md F6 (a), (e): quaternion slot copy, stale CoP frames
+    sim_enabled = True         # run the MuJoCo-subset step (main.py:192-195) after each TSID tick
+    qp_max_iter = 1000         # eiquadprog-fast DEFAULT_MAX_ITER
+    hessian_regularization = 1e-8  # tsid SolverHQuadProgFast default
