@@ -1,0 +1,96 @@
+/* tsidb.h - C-ABI of the MI355X-native batched TSID + contact-dynamics path (libtsidb.so).
+ *
+ * The reference (UW-RoboSoccer/tsid_control) has no FFI for this path: its boundary is the Python
+ * call surface of main.py:119-129,192-195 against ctrl/WalkController.py and ctrl/conf.py.  Each
+ * entry point below names the reference calls it stands for.  All state/output buffers are device
+ * pointers owned by the caller (torch-ROCm tensors), env-major and contiguous, in the arithmetic
+ * type chosen at create time (TSIDB_F64 = the reference's float64, TSIDB_F32); the library owns only
+ * the handle (model constants).  Calls are asynchronous on the given HIP stream (hipStream_t passed
+ * as void*).  Return 0 = OK, non-zero = library-level failure (message via tsidb_last_error);
+ * a per-env QP failure is data in status[e] (tsid HQPStatus codes: 0 optimal, 1 infeasible,
+ * 2 unbounded, 3 max-iter, 4 error), never a call failure - mirroring main.py:122-124 without
+ * aborting the batch.  A handle is not thread-safe; one handle per GPU.
+ */
+#ifndef TSIDB_H
+#define TSIDB_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct tsidb_ctx *tsidb_handle;
+
+enum { TSIDB_F64 = 0, TSIDB_F32 = 1 };
+enum { TSIDB_NQ = 27, TSIDB_NV = 26, TSIDB_NA = 20, TSIDB_NOBS = 65, TSIDB_MAXCON = 32 };
+
+/* parameter vector (float64, host): RobotConfig values the reference hands to its task
+ * constructors (ctrl/conf.py:21-72 via ctrl/WalkController.py:55-184) */
+enum {
+  TSIDB_P_DT = 0, TSIDB_P_MU, TSIDB_P_FMIN, TSIDB_P_FMAX, TSIDB_P_W_FORCEREF, TSIDB_P_KP_CONTACT,
+  TSIDB_P_KD_CONTACT, TSIDB_P_W_FOOT, TSIDB_P_KP_FOOT, TSIDB_P_KD_FOOT, TSIDB_P_W_COM, TSIDB_P_KP_COM,
+  TSIDB_P_KD_COM, TSIDB_P_W_POSTURE, TSIDB_P_HESS_REG, TSIDB_P_QUIRKS, TSIDB_P_NORMAL /*3*/,
+  TSIDB_P_CPOINTS = TSIDB_P_NORMAL + 3 /*4x3*/, TSIDB_P_KP_POSTURE = TSIDB_P_CPOINTS + 12 /*20*/,
+  TSIDB_P_KD_POSTURE = TSIDB_P_KP_POSTURE + 20, TSIDB_P_TAU_MAX = TSIDB_P_KD_POSTURE + 20,
+  TSIDB_P_V_MAX = TSIDB_P_TAU_MAX + 20, TSIDB_P_MAX_ITER = TSIDB_P_V_MAX + 20, TSIDB_P_SIM_ENABLED,
+  TSIDB_P_COUNT = 128
+};
+
+/* WalkController.__init__ (ctrl/WalkController.py:12-187) + MjModel.from_xml_path (main.py:50-52):
+ * parse the compiled model blob (include/tsidb_model.h), derive the constant QP blocks from
+ * `params`, upload to `device`. */
+int tsidb_create(const void *model_blob, size_t nbytes, const double *params, int n_params, int num_envs,
+                 int device, int dtype, tsidb_handle *out);
+int tsidb_destroy(tsidb_handle h);
+const char *tsidb_last_error(tsidb_handle h);
+
+/* RobotConfig edits after construction (the reference edits ctrl/conf.py and rebuilds) */
+int tsidb_set_params(tsidb_handle h, const double *params, int n_params);
+
+/* task references: comTask.setReference (WalkController.py:152), postureTask.setReference (:165),
+ * task_LF/RF.setReference (:195-196), contactLF/RF.setReference (:81,122,240,248), contact on/off
+ * flags (:87,128,225,232,245,253), and the init-time frames get_cop reads (:77,281-282).
+ * com_ref [N,9] pos vel acc; posture_ref [N,20]; foot_ref [N,2,24] = p(3) R col-major(9) v(6) a(6);
+ * contact_ref [N,2,12] = p(3) R col-major(9); contact_active [N,2] u8; cop_frames [N,2,12] =
+ * R row-major(9) p(3).  Pointers are remembered, not copied. */
+int tsidb_set_refs(tsidb_handle h, const void *com_ref, const void *posture_ref, const void *foot_ref,
+                   const void *contact_ref, const uint8_t *contact_active, const void *cop_frames);
+
+/* reset: WalkController.py:22-26,72-79 (standing state, soles onto z = 0), the references of
+ * :81,122,151-152,164-165, and main.py:57-64 (mj_data.qpos = q).  env_ids (device, int32) selects
+ * envs; NULL = all.  Writes state AND the reference buffers registered with tsidb_set_refs. */
+int tsidb_reset(tsidb_handle h, const int32_t *env_ids, int n_ids, void *q, void *v, void *qpos, void *qvel,
+                void *qacc_ws, void *stream);
+
+/* one TSID tick for every env: main.py:119-129 (+ readouts :132-142).
+ * q [N,27], v [N,26] updated in place; tau [N,20], dv [N,26], f [N,24] (LF 12, RF 12), status [N],
+ * obs [N,65] = q v com cop LF RF (may be NULL), frames [N,2,12] sole placements R row-major + p
+ * (may be NULL), info [N,4] int32 = qp iterations, active-set size, -, - (may be NULL). */
+int tsidb_tick(tsidb_handle h, void *q, void *v, void *tau, void *dv, void *f, int32_t *status, void *obs,
+               void *frames, int32_t *info, void *stream);
+
+/* one sim step for every env: main.py:192-195.  q_tsid [N,27] (NULL = no teleport, ctrl = 0),
+ * qpos [N,27], qvel [N,26], qacc_ws [N,26] updated in place; qacc [N,26], ncon [N],
+ * con_pairs [N,32] = (body << 16 | hull vertex), -1 padded; info [N,4] slots 2,3 = solver
+ * iterations, failure bits (all may be NULL). */
+int tsidb_sim(tsidb_handle h, const void *q_tsid, void *qpos, void *qvel, void *qacc_ws, void *qacc,
+              int32_t *ncon, int32_t *con_pairs, int32_t *info, void *stream);
+
+/* whole env step, n_substeps times: tsidb_tick then (if params[SIM_ENABLED]) tsidb_sim. */
+int tsidb_step(tsidb_handle h, void *q, void *v, void *qpos, void *qvel, void *qacc_ws, void *tau, void *dv,
+               void *f, int32_t *status, void *obs, void *frames, int32_t *ncon, int32_t *con_pairs,
+               int32_t *info, int n_substeps, void *stream);
+
+/* probe of formulation.computeProblemData's rigid-body terms (main.py:119): M [N,26,26],
+ * hbias [N,26], Jcom [N,3,26], Jf [N,2,6,26] (LOCAL), oMf [N,2,12], com [N,3].  Test/debug use. */
+int tsidb_rbd_terms(tsidb_handle h, const void *q, const void *v, void *M, void *hbias, void *Jcom, void *Jf,
+                    void *oMf, void *com, void *stream);
+
+/* bytes of LDS one env occupies in kernel `which` (0 tick, 1 sim) for `dtype` */
+int tsidb_lds_bytes(int dtype, int which);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

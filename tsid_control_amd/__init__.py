@@ -1,0 +1,13 @@
+"""MI355X-native batched TSID + contact-dynamics hot path of UW-RoboSoccer/tsid_control.
+
+Host surface: RobotConfig (ctrl/conf.py) and WalkController (ctrl/WalkController.py) with
+reset()/step(); compute: hand-written HIP kernels behind the C-ABI in include/tsidb.h.
+"""
+from .conf import RobotConfig  # noqa: F401
+
+
+def __getattr__(name):
+    if name in ("WalkController", "TrajectorySample", "map_tsid_to_mujoco"):
+        from . import walk_controller
+        return getattr(walk_controller, name)
+    raise AttributeError(name)

@@ -1,0 +1,51 @@
+"""ctypes binding of libtsidb.so (include/tsidb.h).  There is no CPU fallback: if the HIP library
+is missing or a call fails, this raises."""
+import ctypes as C
+from pathlib import Path
+
+_HERE = Path(__file__).parent
+LIB_PATH = _HERE / "libtsidb.so"
+
+SYMBOLS = ["tsidb_create", "tsidb_destroy", "tsidb_last_error", "tsidb_set_params", "tsidb_set_refs", "tsidb_reset",
+           "tsidb_tick", "tsidb_sim", "tsidb_step", "tsidb_rbd_terms", "tsidb_lds_bytes"]
+
+_lib = None
+
+
+class TsidbError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libtsidb.so once; raise loudly when it has not been built (python __graft_entry__.py build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise TsidbError(f"{LIB_PATH} is missing: build the HIP extension first "
+                         "(python -c 'import __graft_entry__ as g; g.build()'); there is no CPU path")
+    L = C.CDLL(str(LIB_PATH))
+    vp, i32p = C.c_void_p, C.c_void_p
+    L.tsidb_create.argtypes = [vp, C.c_size_t, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+    L.tsidb_destroy.argtypes = [vp]
+    L.tsidb_last_error.argtypes = [vp]
+    L.tsidb_last_error.restype = C.c_char_p
+    L.tsidb_set_params.argtypes = [vp, vp, C.c_int]
+    L.tsidb_set_refs.argtypes = [vp] * 7
+    L.tsidb_reset.argtypes = [vp, i32p, C.c_int, vp, vp, vp, vp, vp, vp]
+    L.tsidb_tick.argtypes = [vp] * 11
+    L.tsidb_sim.argtypes = [vp] * 10
+    L.tsidb_step.argtypes = [vp] * 15 + [C.c_int, vp]
+    L.tsidb_rbd_terms.argtypes = [vp] * 10
+    L.tsidb_lds_bytes.argtypes = [C.c_int, C.c_int]
+    for s in SYMBOLS:
+        if s != "tsidb_last_error":
+            getattr(L, s).restype = C.c_int
+    _lib = L
+    return L
+
+
+def check(L, handle, rc, what):
+    if rc != 0:
+        msg = L.tsidb_last_error(handle)
+        raise TsidbError(f"{what} failed (rc={rc}): {msg.decode() if msg else '?'}")

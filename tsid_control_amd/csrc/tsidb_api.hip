@@ -1,0 +1,517 @@
+// tsidb_api.hip - kernels and the C-ABI of libtsidb.so (include/tsidb.h).  gfx950 only.
+#include "../../include/tsidb.h"
+#include "tsidb_common.hpp"
+#include "tsidb_sim.hpp"
+#include "tsidb_tick.hpp"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace tsidb;
+
+// ============================================================================ kernels
+template <typename T>
+__global__ __launch_bounds__(WAVE) void k_tick(const DevModel<T> *__restrict__ mp, int n, T *q, T *v, const T *com_ref,
+                                               const T *posture_ref, const T *foot_ref, const T *contact_ref,
+                                               const uint8_t *cact, const T *cop_frames, T *tau, T *dv, T *f,
+                                               int *status, T *obs, T *frames, int *info) {
+  __shared__ TickLds<T> L;
+  const int e = blockIdx.x, lane = threadIdx.x;
+  if (e >= n) return;
+  const size_t E = (size_t)e;
+  tsid_tick_env<T>(*mp, L, lane, q + E * NQ, v + E * NV, com_ref + E * 9, posture_ref + E * NA, foot_ref + E * 48,
+                   contact_ref + E * 24, cact + E * 2, cop_frames ? cop_frames + E * 24 : nullptr, tau + E * NA,
+                   dv + E * NV, f + E * 24, status + e, obs ? obs + E * NOBS : nullptr, info ? info + E * 4 : nullptr);
+  if (frames && lane < 24) frames[E * 24 + lane] = L.oMf[lane / 12][lane % 12];
+}
+
+template <typename T>
+__global__ __launch_bounds__(WAVE) void k_sim(const DevModel<T> *__restrict__ mp, int n, const T *q_tsid, T *qpos, T *qvel,
+                                              T *qacc_ws, T *qacc, int *ncon, int *con, int *info) {
+  __shared__ SimLds<T> L;
+  const int e = blockIdx.x, lane = threadIdx.x;
+  if (e >= n) return;
+  const size_t E = (size_t)e;
+  sim_step_env<T>(*mp, L, lane, q_tsid ? q_tsid + E * NQ : nullptr, qpos + E * NQ, qvel + E * NV, qacc_ws + E * NV,
+                  qacc ? qacc + E * NV : nullptr, ncon ? ncon + e : nullptr, con ? con + E * MAXCON : nullptr,
+                  info ? info + E * 4 : nullptr);
+}
+
+template <typename T>
+__global__ __launch_bounds__(WAVE) void k_rbd(const DevModel<T> *__restrict__ mp, int n, const T *q, const T *v, T *M, T *hb,
+                                              T *Jcom, T *Jf, T *oMf, T *com) {
+  __shared__ TickLds<T> L;
+  const int e = blockIdx.x, lane = threadIdx.x;
+  if (e >= n) return;
+  const size_t E = (size_t)e;
+  if (lane < NQ) L.qs[lane] = q[E * NQ + lane];
+  if (lane < NV) L.vs[lane] = v[E * NV + lane];
+  __syncthreads();
+  rbd_terms<T>(*mp, L, lane);
+  for (int i = lane; i < NV * NV; i += WAVE) M[E * NV * NV + i] = L.Dyn[(i / NV) * LDD + i % NV];
+  if (lane < NV) hb[E * NV + lane] = L.h[lane];
+  for (int i = lane; i < 3 * NV; i += WAVE) Jcom[E * 3 * NV + i] = L.Jcom[(i / NV) * LDF + i % NV];
+  for (int i = lane; i < 12 * NV; i += WAVE) Jf[E * 12 * NV + i] = L.Jf[(i / NV) * LDF + i % NV];
+  if (lane < 24) oMf[E * 24 + lane] = L.oMf[lane / 12][lane % 12];
+  if (lane < 3) com[E * 3 + lane] = L.com[lane];
+}
+
+// reset: standing state + references (WalkController.py:22-26,72-79,81,122,151-152,164-165; main.py:57-64)
+template <typename T>
+__global__ __launch_bounds__(WAVE) void k_reset(const DevModel<T> *__restrict__ mp, int n, const int *env_ids, int n_ids, T *q,
+                                                T *v, T *qpos, T *qvel, T *qacc_ws, T *com_ref, T *posture_ref,
+                                                T *foot_ref, T *contact_ref, uint8_t *cact, T *cop_frames) {
+  __shared__ TickLds<T> L;
+  const DevModel<T> &m = *mp;
+  const int lane = threadIdx.x;
+  int e = blockIdx.x;
+  if (env_ids) {
+    if (e >= n_ids) return;
+    e = env_ids[e];
+  }
+  if (e < 0 || e >= n) return;
+  const size_t E = (size_t)e;
+  if (lane < NQ) L.qs[lane] = m.q0[lane];
+  if (lane < NV) L.vs[lane] = 0;
+  __syncthreads();
+  rbd_terms<T>(m, L, lane);
+  const T zlf = L.oMf[0][11];
+  __syncthreads();
+  if (lane == 0) L.qs[2] -= zlf; // WalkController.py:74
+  __syncthreads();
+  rbd_terms<T>(m, L, lane);
+  if (lane < NQ) q[E * NQ + lane] = L.qs[lane];
+  if (lane < NV) { v[E * NV + lane] = 0; qvel[E * NV + lane] = 0; qacc_ws[E * NV + lane] = 0; }
+  if (lane < NQ) {
+    T val = L.qs[lane]; // main.py:64: raw copy (quirks F6a/F6b); joints are all zero in "standing"
+    if (m.params[P_QUIRKS] == 0) {
+      if (lane == 3) val = L.qs[6];
+      else if (lane > 3 && lane < 7) val = L.qs[lane - 1];
+      else if (lane >= 7) val = L.qs[m.mj_ctrl_qidx[lane - 7]];
+    }
+    qpos[E * NQ + lane] = val;
+  }
+  if (lane < 24) {
+    const int f = lane / 12, i = lane % 12;
+    // SE3ToVector layout: p(3), R column-major(9)
+    T val = i < 3 ? L.oMf[f][9 + i] : L.oMf[f][3 * ((i - 3) % 3) + (i - 3) / 3];
+    contact_ref[E * 24 + lane] = val;
+    cop_frames[E * 24 + lane] = L.oMf[f][i];
+  }
+  if (lane < 48) {
+    const int i = lane % 24;
+    // foot tasks never get a reference in the reference (quirk F6c): identity placement
+    foot_ref[E * 48 + lane] = (i == 3 || i == 7 || i == 11) ? T(1) : T(0);
+  }
+  if (lane < 9) com_ref[E * 9 + lane] = lane < 3 ? L.com[lane] : T(0);
+  if (lane < NA) posture_ref[E * NA + lane] = L.qs[7 + lane];
+  if (lane < 2) cact[E * 2 + lane] = 1;
+}
+
+// ============================================================================ host side
+namespace {
+
+struct Sect {
+  char name[24];
+  uint32_t dtype, count;
+  uint64_t offset;
+};
+
+struct Blob {
+  std::vector<uint8_t> raw;
+  const Sect *find(const char *name) const {
+    uint32_t n;
+    memcpy(&n, raw.data() + 8, 4);
+    const Sect *s = (const Sect *)(raw.data() + 16);
+    for (uint32_t i = 0; i < n; i++)
+      if (strncmp(s[i].name, name, 24) == 0) return &s[i];
+    return nullptr;
+  }
+  const double *f64(const char *name, uint32_t cnt) const {
+    const Sect *s = find(name);
+    if (!s || s->dtype != 0 || (cnt && s->count != cnt)) throw std::string("model blob: bad section ") + name;
+    return (const double *)(raw.data() + s->offset);
+  }
+  const int *i32(const char *name, uint32_t cnt) const {
+    const Sect *s = find(name);
+    if (!s || s->dtype != 1 || (cnt && s->count != cnt)) throw std::string("model blob: bad section ") + name;
+    return (const int *)(raw.data() + s->offset);
+  }
+  uint32_t count(const char *name) const {
+    const Sect *s = find(name);
+    return s ? s->count : 0;
+  }
+};
+
+void quat_wxyz_to_R_host(const double *q, double *R) {
+  double w = q[0], x = q[1], y = q[2], z = q[3], n = 1.0 / std::sqrt(w * w + x * x + y * y + z * z);
+  w *= n; x *= n; y *= n; z *= n;
+  R[0] = 1 - 2 * (y * y + z * z); R[1] = 2 * (x * y - w * z); R[2] = 2 * (x * z + w * y);
+  R[3] = 2 * (x * y + w * z); R[4] = 1 - 2 * (x * x + z * z); R[5] = 2 * (y * z - w * x);
+  R[6] = 2 * (x * z - w * y); R[7] = 2 * (y * z + w * x); R[8] = 1 - 2 * (x * x + y * y);
+}
+
+void tree_tables(const int *parent, int n, int *depth, int *nchild, int (*child)[MAXCHILD], unsigned *anc, int *maxdepth) {
+  *maxdepth = 0;
+  for (int j = 0; j < n; j++) {
+    nchild[j] = 0;
+    depth[j] = parent[j] < 0 ? 0 : depth[parent[j]] + 1;
+    anc[j] = (parent[j] < 0 ? 0u : anc[parent[j]]) | (1u << j);
+    if (depth[j] > *maxdepth) *maxdepth = depth[j];
+  }
+  for (int j = 0; j < n; j++)
+    if (parent[j] >= 0) {
+      int p = parent[j];
+      if (nchild[p] >= MAXCHILD) throw std::string("model blob: too many children per body");
+      child[p][nchild[p]++] = j;
+    }
+}
+
+} // namespace
+
+struct tsidb_ctx {
+  int device = 0, dtype = 0, num_envs = 0;
+  Blob blob;
+  std::vector<double> params;
+  void *d_model = nullptr, *d_hull = nullptr;
+  int *d_eadr = nullptr, *d_edge = nullptr;
+  const void *com_ref = nullptr, *posture_ref = nullptr, *foot_ref = nullptr, *contact_ref = nullptr, *cop_frames = nullptr;
+  const uint8_t *contact_active = nullptr;
+  std::string err;
+};
+
+#define HIP_OK(call)                                                                  \
+  do {                                                                                \
+    hipError_t e_ = (call);                                                           \
+    if (e_ != hipSuccess) throw std::string(#call " failed: ") + hipGetErrorString(e_); \
+  } while (0)
+
+template <typename T>
+static void build_model(tsidb_ctx *h, DevModel<T> &m) {
+  const Blob &b = h->blob;
+  memset(&m, 0, sizeof m);
+  // ---- TSID side
+  memcpy(m.pin_parent, b.i32("pin_parent", NJ), sizeof m.pin_parent);
+  tree_tables(m.pin_parent, NJ, m.pin_depth, m.pin_nchild, m.pin_child, m.pin_anc, &m.pin_maxdepth);
+  const double *pl = b.f64("pin_place", NJ * 12), *in = b.f64("pin_inertia", NJ * 10);
+  double mass = 0;
+  for (int j = 0; j < NJ; j++) {
+    for (int i = 0; i < 12; i++) m.pin_place[j][i] = (T)pl[12 * j + i];
+    for (int i = 0; i < 10; i++) m.pin_inertia[j][i] = (T)in[10 * j + i];
+    mass += in[10 * j];
+  }
+  m.mass = (T)mass;
+  memcpy(m.frame_parent, b.i32("pin_frame_parent", 2), sizeof m.frame_parent);
+  const double *fp = b.f64("pin_frame_place", 24), *q0 = b.f64("pin_q0", NQ);
+  for (int i = 0; i < 24; i++) m.frame_place[i / 12][i % 12] = (T)fp[i];
+  for (int i = 0; i < NQ; i++) m.q0[i] = (T)q0[i];
+  // ---- parameters and the constant QP blocks derived from them
+  const double *P = h->params.data();
+  for (int i = 0; i < P_COUNT; i++) m.params[i] = (T)P[i];
+  double Tg[6][12] = {{0}};
+  for (int i = 0; i < 4; i++) {
+    const double *p = P + P_CPOINTS + 3 * i;
+    for (int k = 0; k < 3; k++) Tg[k][3 * i + k] = 1.0;
+    Tg[3][3 * i + 1] = -p[2]; Tg[3][3 * i + 2] = p[1];
+    Tg[4][3 * i + 0] = p[2];  Tg[4][3 * i + 2] = -p[0];
+    Tg[5][3 * i + 0] = -p[1]; Tg[5][3 * i + 1] = p[0];
+  }
+  for (int i = 0; i < 6; i++) for (int c = 0; c < 12; c++) m.Tgen[i][c] = (T)Tg[i][c];
+  { // friction pyramid (Contact6d::updateForceInequalityConstraints)
+    const double *n = P + P_NORMAL, mu = P[P_MU];
+    auto cr = [](const double *a, const double *c, double *o) {
+      o[0] = a[1] * c[2] - a[2] * c[1]; o[1] = a[2] * c[0] - a[0] * c[2]; o[2] = a[0] * c[1] - a[1] * c[0];
+    };
+    double ex[3] = {1, 0, 0}, ey[3] = {0, 1, 0}, t1[3], t2[3];
+    cr(n, ex, t1);
+    if (std::sqrt(t1[0] * t1[0] + t1[1] * t1[1] + t1[2] * t1[2]) < 1e-5) cr(n, ey, t1);
+    cr(n, t1, t2);
+    double n1 = std::sqrt(t1[0] * t1[0] + t1[1] * t1[1] + t1[2] * t1[2]), n2 = std::sqrt(t2[0] * t2[0] + t2[1] * t2[1] + t2[2] * t2[2]);
+    for (int i = 0; i < 3; i++) { t1[i] /= n1; t2[i] /= n2; }
+    for (int i = 0; i < 4; i++)
+      for (int k = 0; k < 3; k++) {
+        m.Bcone[4 * i + 0][3 * i + k] = (T)(-t1[k] - mu * n[k]);
+        m.Bcone[4 * i + 1][3 * i + k] = (T)(t1[k] - mu * n[k]);
+        m.Bcone[4 * i + 2][3 * i + k] = (T)(-t2[k] - mu * n[k]);
+        m.Bcone[4 * i + 3][3 * i + k] = (T)(t2[k] - mu * n[k]);
+        m.Bcone[16][3 * i + k] = (T)n[k];
+      }
+    for (int i = 0; i < 16; i++) { m.cone_lb[i] = (T)-1e10; m.cone_ub[i] = 0; }
+    m.cone_lb[16] = (T)P[P_FMIN];
+    m.cone_ub[16] = (T)P[P_FMAX];
+  }
+  { // force-regularisation Hessian block: w (W T)^T (W T) + reg I, its Cholesky factor inverse-transposed
+    const double wreg[6] = {1, 1, 1e-3, 2, 2, 2};
+    double Hf[12][12] = {{0}}, Lf[12][12] = {{0}}, X[12][12] = {{0}};
+    for (int a = 0; a < 12; a++)
+      for (int c = 0; c < 12; c++) {
+        double s = 0;
+        for (int i = 0; i < 6; i++) s += wreg[i] * Tg[i][a] * wreg[i] * Tg[i][c];
+        Hf[a][c] = P[P_W_FORCEREF] * s + (a == c ? P[P_HESS_REG] : 0.0);
+      }
+    double tr = 0;
+    for (int a = 0; a < 12; a++) tr += Hf[a][a];
+    for (int j = 0; j < 12; j++) {
+      double s = Hf[j][j];
+      for (int k = 0; k < j; k++) s -= Lf[j][k] * Lf[j][k];
+      if (!(s > 0)) throw std::string("force-regularisation block is not positive definite");
+      Lf[j][j] = std::sqrt(s);
+      for (int i = j + 1; i < 12; i++) {
+        double t = Hf[i][j];
+        for (int k = 0; k < j; k++) t -= Lf[i][k] * Lf[j][k];
+        Lf[i][j] = t / Lf[j][j];
+      }
+    }
+    for (int c = 0; c < 12; c++) // X = L^-1 by forward substitution
+      for (int i = 0; i < 12; i++) {
+        double s = i == c ? 1.0 : 0.0;
+        for (int k = 0; k < i; k++) s -= Lf[i][k] * X[k][c];
+        X[i][c] = s / Lf[i][i];
+      }
+    double trJ = 0;
+    for (int a = 0; a < 12; a++) {
+      for (int c = 0; c < 12; c++) m.Jf0[a][c] = (T)X[c][a]; // L^-T
+      trJ += X[a][a];
+    }
+    m.Hf_trace = (T)tr;
+    m.Jf0_trace = (T)trJ;
+  }
+  // ---- sim side
+  memcpy(m.mj_parent, b.i32("mj_parent", NB), sizeof m.mj_parent);
+  tree_tables(m.mj_parent, NB, m.mj_depth, m.mj_nchild, m.mj_child, m.mj_anc, &m.mj_maxdepth);
+  const double *mp = b.f64("mj_pos", NB * 3), *mq = b.f64("mj_quat", NB * 4), *mi = b.f64("mj_inertia", NB * 10);
+  for (int j = 0; j < NB; j++) {
+    double R[9];
+    quat_wxyz_to_R_host(mq + 4 * j, R);
+    for (int i = 0; i < 9; i++) m.mj_R[j][i] = (T)R[i];
+    for (int i = 0; i < 3; i++) m.mj_pos[j][i] = (T)mp[3 * j + i];
+    for (int i = 0; i < 10; i++) m.mj_inertia[j][i] = (T)mi[10 * j + i];
+  }
+  const double *arm = b.f64("mj_armature", NV), *fl = b.f64("mj_frictionloss", NV), *iw = b.f64("mj_dof_invw0", NV);
+  const double *bw = b.f64("mj_body_invw0", NB * 2), *M0 = b.f64("mj_dof_M0", NV);
+  double mean = 0;
+  for (int i = 0; i < NV; i++) {
+    m.mj_armature[i] = (T)arm[i]; m.mj_frictionloss[i] = (T)fl[i]; m.mj_dof_invw0[i] = (T)iw[i];
+    mean += M0[i];
+  }
+  m.meaninertia = (T)(mean / NV);
+  for (int i = 0; i < NB * 2; i++) m.mj_body_invw0[i / 2][i % 2] = (T)bw[i];
+  memcpy(m.mj_act_dof, b.i32("mj_act_dof", NA), sizeof m.mj_act_dof);
+  memcpy(m.mj_ctrl_qidx, b.i32("mj_ctrl_qidx", NA), sizeof m.mj_ctrl_qidx);
+  const double *kp = b.f64("mj_act_kp", NA), *kv = b.f64("mj_act_kv", NA);
+  for (int i = 0; i < NA; i++) { m.mj_act_kp[i] = (T)kp[i]; m.mj_act_kv[i] = (T)kv[i]; }
+  memcpy(m.hull_adr, b.i32("mj_hull_adr", NB + 1), sizeof m.hull_adr);
+  const double *rb = b.f64("mj_rbound", NB * 4), *op = b.f64("mj_opt", 7), *ct = b.f64("mj_contact", 8);
+  for (int i = 0; i < NB * 4; i++) m.rbound[i / 4][i % 4] = (T)rb[i];
+  for (int i = 0; i < 7; i++) m.opt[i] = (T)op[i];
+  m.opt[0] = (T)P[P_DT];                         // main.py:52 mj_model.opt.timestep = conf.dt
+  m.opt[6] = sizeof(T) == 8 ? (T)1e-9 : (T)2e-6; // support-vertex tie tolerance
+  for (int i = 0; i < 8; i++) m.contact[i] = (T)ct[i];
+  m.hull_vert = (const T *)h->d_hull;
+  m.hull_eadr = h->d_eadr;
+  m.hull_edge = h->d_edge;
+}
+
+template <typename T>
+static void upload_model(tsidb_ctx *h) {
+  const Blob &b = h->blob;
+  if (!h->d_hull) {
+    const uint32_t nvert3 = b.count("mj_hull_vert"), nedge = b.count("mj_hull_edge"), neadr = b.count("mj_hull_eadr");
+    const double *hv = b.f64("mj_hull_vert", 0);
+    std::vector<T> hvt(nvert3);
+    for (uint32_t i = 0; i < nvert3; i++) hvt[i] = (T)hv[i];
+    HIP_OK(hipMalloc(&h->d_hull, nvert3 * sizeof(T)));
+    HIP_OK(hipMemcpy(h->d_hull, hvt.data(), nvert3 * sizeof(T), hipMemcpyHostToDevice));
+    HIP_OK(hipMalloc((void **)&h->d_eadr, neadr * sizeof(int)));
+    HIP_OK(hipMemcpy(h->d_eadr, b.i32("mj_hull_eadr", 0), neadr * sizeof(int), hipMemcpyHostToDevice));
+    HIP_OK(hipMalloc((void **)&h->d_edge, nedge * sizeof(int)));
+    HIP_OK(hipMemcpy(h->d_edge, b.i32("mj_hull_edge", 0), nedge * sizeof(int), hipMemcpyHostToDevice));
+    HIP_OK(hipMalloc(&h->d_model, sizeof(DevModel<T>)));
+  }
+  static thread_local DevModel<T> m;
+  build_model<T>(h, m);
+  HIP_OK(hipMemcpy(h->d_model, &m, sizeof m, hipMemcpyHostToDevice));
+}
+
+#define GUARD_BEGIN                      \
+  if (!h) return -1;                     \
+  try {                                  \
+    HIP_OK(hipSetDevice(h->device));
+#define GUARD_END                        \
+  }                                      \
+  catch (const std::string &s) {         \
+    h->err = s;                          \
+    return 1;                            \
+  }                                      \
+  return 0;
+
+static void need_refs(tsidb_ctx *h) {
+  if (!h->com_ref) throw std::string("reference buffers not registered (call tsidb_set_refs first)");
+}
+
+template <typename T>
+static void launch_tick(tsidb_ctx *h, void *q, void *v, void *tau, void *dv, void *f, int32_t *status, void *obs,
+                        void *frames, int32_t *info, hipStream_t s) {
+  hipLaunchKernelGGL(k_tick<T>, dim3(h->num_envs), dim3(WAVE), 0, s, (const DevModel<T> *)h->d_model, h->num_envs, (T *)q,
+                     (T *)v, (const T *)h->com_ref, (const T *)h->posture_ref, (const T *)h->foot_ref,
+                     (const T *)h->contact_ref, h->contact_active, (const T *)h->cop_frames, (T *)tau, (T *)dv, (T *)f,
+                     status, (T *)obs, (T *)frames, info);
+  HIP_OK(hipGetLastError());
+}
+template <typename T>
+static void launch_sim(tsidb_ctx *h, const void *q_tsid, void *qpos, void *qvel, void *qacc_ws, void *qacc, int32_t *ncon,
+                       int32_t *con, int32_t *info, hipStream_t s) {
+  hipLaunchKernelGGL(k_sim<T>, dim3(h->num_envs), dim3(WAVE), 0, s, (const DevModel<T> *)h->d_model, h->num_envs,
+                     (const T *)q_tsid, (T *)qpos, (T *)qvel, (T *)qacc_ws, (T *)qacc, ncon, con, info);
+  HIP_OK(hipGetLastError());
+}
+
+extern "C" {
+
+int tsidb_create(const void *model_blob, size_t nbytes, const double *params, int n_params, int num_envs, int device,
+                 int dtype, tsidb_handle *out) {
+  if (!out) return -1;
+  *out = nullptr;
+  tsidb_ctx *h = new tsidb_ctx();
+  *out = h; // returned even on failure so that tsidb_last_error can be read; caller destroys it
+  try {
+    if (!model_blob || nbytes < 16 || memcmp(model_blob, "TSIDBM01", 8) != 0) throw std::string("not a TSIDBM01 model blob");
+    if (!params || n_params != P_COUNT) throw std::string("params must hold TSIDB_P_COUNT doubles");
+    if (num_envs <= 0) throw std::string("num_envs must be positive");
+    if (dtype != TSIDB_F64 && dtype != TSIDB_F32) throw std::string("dtype must be TSIDB_F64 or TSIDB_F32");
+    h->device = device; h->dtype = dtype; h->num_envs = num_envs;
+    h->blob.raw.assign((const uint8_t *)model_blob, (const uint8_t *)model_blob + nbytes);
+    h->params.assign(params, params + n_params);
+    int ndev = 0;
+    HIP_OK(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) throw std::string("no such HIP device (this library has no CPU path)");
+    HIP_OK(hipSetDevice(device));
+    if (dtype == TSIDB_F64) upload_model<double>(h); else upload_model<float>(h);
+  } catch (const std::string &s) {
+    h->err = s;
+    return 1;
+  }
+  return 0;
+}
+
+int tsidb_destroy(tsidb_handle h) {
+  if (!h) return -1;
+  if (h->d_model) {
+    (void)hipSetDevice(h->device);
+    (void)hipFree(h->d_model); (void)hipFree(h->d_hull); (void)hipFree(h->d_eadr); (void)hipFree(h->d_edge);
+  }
+  delete h;
+  return 0;
+}
+
+const char *tsidb_last_error(tsidb_handle h) { return h ? h->err.c_str() : "null handle"; }
+
+int tsidb_set_params(tsidb_handle h, const double *params, int n_params) {
+  GUARD_BEGIN
+  if (!params || n_params != P_COUNT) throw std::string("params must hold TSIDB_P_COUNT doubles");
+  h->params.assign(params, params + n_params);
+  HIP_OK(hipDeviceSynchronize());
+  if (h->dtype == TSIDB_F64) upload_model<double>(h); else upload_model<float>(h);
+  GUARD_END
+}
+
+int tsidb_set_refs(tsidb_handle h, const void *com_ref, const void *posture_ref, const void *foot_ref,
+                   const void *contact_ref, const uint8_t *contact_active, const void *cop_frames) {
+  if (!h) return -1;
+  if (!com_ref || !posture_ref || !foot_ref || !contact_ref || !contact_active || !cop_frames) {
+    h->err = "tsidb_set_refs: null reference buffer";
+    return 1;
+  }
+  h->com_ref = com_ref; h->posture_ref = posture_ref; h->foot_ref = foot_ref;
+  h->contact_ref = contact_ref; h->contact_active = contact_active; h->cop_frames = cop_frames;
+  return 0;
+}
+
+int tsidb_reset(tsidb_handle h, const int32_t *env_ids, int n_ids, void *q, void *v, void *qpos, void *qvel,
+                void *qacc_ws, void *stream) {
+  GUARD_BEGIN
+  need_refs(h);
+  if (!q || !v || !qpos || !qvel || !qacc_ws) throw std::string("tsidb_reset: null state buffer");
+  const int grid = env_ids ? n_ids : h->num_envs;
+  if (grid <= 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  if (h->dtype == TSIDB_F64)
+    hipLaunchKernelGGL(k_reset<double>, dim3(grid), dim3(WAVE), 0, s, (const DevModel<double> *)h->d_model, h->num_envs,
+                       env_ids, n_ids, (double *)q, (double *)v, (double *)qpos, (double *)qvel, (double *)qacc_ws,
+                       (double *)h->com_ref, (double *)h->posture_ref, (double *)h->foot_ref, (double *)h->contact_ref,
+                       (uint8_t *)h->contact_active, (double *)h->cop_frames);
+  else
+    hipLaunchKernelGGL(k_reset<float>, dim3(grid), dim3(WAVE), 0, s, (const DevModel<float> *)h->d_model, h->num_envs,
+                       env_ids, n_ids, (float *)q, (float *)v, (float *)qpos, (float *)qvel, (float *)qacc_ws,
+                       (float *)h->com_ref, (float *)h->posture_ref, (float *)h->foot_ref, (float *)h->contact_ref,
+                       (uint8_t *)h->contact_active, (float *)h->cop_frames);
+  HIP_OK(hipGetLastError());
+  GUARD_END
+}
+
+int tsidb_tick(tsidb_handle h, void *q, void *v, void *tau, void *dv, void *f, int32_t *status, void *obs, void *frames,
+               int32_t *info, void *stream) {
+  GUARD_BEGIN
+  need_refs(h);
+  if (!q || !v || !tau || !dv || !f || !status) throw std::string("tsidb_tick: null buffer");
+  if (h->dtype == TSIDB_F64) launch_tick<double>(h, q, v, tau, dv, f, status, obs, frames, info, (hipStream_t)stream);
+  else launch_tick<float>(h, q, v, tau, dv, f, status, obs, frames, info, (hipStream_t)stream);
+  GUARD_END
+}
+
+int tsidb_sim(tsidb_handle h, const void *q_tsid, void *qpos, void *qvel, void *qacc_ws, void *qacc, int32_t *ncon,
+              int32_t *con_pairs, int32_t *info, void *stream) {
+  GUARD_BEGIN
+  if (!qpos || !qvel || !qacc_ws) throw std::string("tsidb_sim: null state buffer");
+  if (h->dtype == TSIDB_F64) launch_sim<double>(h, q_tsid, qpos, qvel, qacc_ws, qacc, ncon, con_pairs, info, (hipStream_t)stream);
+  else launch_sim<float>(h, q_tsid, qpos, qvel, qacc_ws, qacc, ncon, con_pairs, info, (hipStream_t)stream);
+  GUARD_END
+}
+
+int tsidb_step(tsidb_handle h, void *q, void *v, void *qpos, void *qvel, void *qacc_ws, void *tau, void *dv, void *f,
+               int32_t *status, void *obs, void *frames, int32_t *ncon, int32_t *con_pairs, int32_t *info, int n_substeps,
+               void *stream) {
+  GUARD_BEGIN
+  need_refs(h);
+  if (!q || !v || !tau || !dv || !f || !status) throw std::string("tsidb_step: null buffer");
+  const bool sim = h->params[P_SIM_ENABLED] != 0.0;
+  if (sim && (!qpos || !qvel || !qacc_ws)) throw std::string("tsidb_step: null sim state buffer");
+  hipStream_t s = (hipStream_t)stream;
+  for (int it = 0; it < n_substeps; it++) {
+    if (h->dtype == TSIDB_F64) {
+      launch_tick<double>(h, q, v, tau, dv, f, status, obs, frames, info, s);
+      if (sim) launch_sim<double>(h, q, qpos, qvel, qacc_ws, nullptr, ncon, con_pairs, info, s);
+    } else {
+      launch_tick<float>(h, q, v, tau, dv, f, status, obs, frames, info, s);
+      if (sim) launch_sim<float>(h, q, qpos, qvel, qacc_ws, nullptr, ncon, con_pairs, info, s);
+    }
+  }
+  GUARD_END
+}
+
+int tsidb_rbd_terms(tsidb_handle h, const void *q, const void *v, void *M, void *hbias, void *Jcom, void *Jf, void *oMf,
+                    void *com, void *stream) {
+  GUARD_BEGIN
+  if (!q || !v || !M || !hbias || !Jcom || !Jf || !oMf || !com) throw std::string("tsidb_rbd_terms: null buffer");
+  hipStream_t s = (hipStream_t)stream;
+  if (h->dtype == TSIDB_F64)
+    hipLaunchKernelGGL(k_rbd<double>, dim3(h->num_envs), dim3(WAVE), 0, s, (const DevModel<double> *)h->d_model, h->num_envs,
+                       (const double *)q, (const double *)v, (double *)M, (double *)hbias, (double *)Jcom, (double *)Jf,
+                       (double *)oMf, (double *)com);
+  else
+    hipLaunchKernelGGL(k_rbd<float>, dim3(h->num_envs), dim3(WAVE), 0, s, (const DevModel<float> *)h->d_model, h->num_envs,
+                       (const float *)q, (const float *)v, (float *)M, (float *)hbias, (float *)Jcom, (float *)Jf,
+                       (float *)oMf, (float *)com);
+  HIP_OK(hipGetLastError());
+  GUARD_END
+}
+
+int tsidb_lds_bytes(int dtype, int which) {
+  if (dtype == TSIDB_F64) return which == 0 ? (int)sizeof(TickLds<double>) : (int)sizeof(SimLds<double>);
+  return which == 0 ? (int)sizeof(TickLds<float>) : (int)sizeof(SimLds<float>);
+}
+
+} // extern "C"

@@ -1,0 +1,197 @@
+// tsidb_common.hpp - shared device-side definitions for the batched TSID + contact-dynamics path.
+// gfx950 only: 64-lane wavefronts, one wavefront (= one workgroup) per env.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace tsidb {
+
+constexpr int NJ = 21;   // TSID joints incl. the free-flyer root (pinocchio order)
+constexpr int NQ = 27;
+constexpr int NV = 26;
+constexpr int NA = 20;
+constexpr int NB = 21;   // sim bodies (MuJoCo document order, world excluded)
+constexpr int NVAR = 50; // [dv(26); f_slot0(12); f_slot1(12)]
+constexpr int LDJ = 51;  // padded leading dimension of the 50x50 J factor in LDS
+constexpr int LDD = 51;  // leading dimension of the dynamics rows [M | -Jc^T]
+constexpr int LDF = 27;  // leading dimension of frame / CoM Jacobians
+constexpr int NOBS = 65;
+constexpr int MAXCON = 32;
+constexpr int MAXCHILD = 6;
+constexpr int WAVE = 64;
+
+// parameter vector indices: mirror of include/tsidb.h TSIDB_P_*
+enum {
+  P_DT = 0, P_MU, P_FMIN, P_FMAX, P_W_FORCEREF, P_KP_CONTACT, P_KD_CONTACT, P_W_FOOT, P_KP_FOOT, P_KD_FOOT,
+  P_W_COM, P_KP_COM, P_KD_COM, P_W_POSTURE, P_HESS_REG, P_QUIRKS, P_NORMAL, P_CPOINTS = P_NORMAL + 3,
+  P_KP_POSTURE = P_CPOINTS + 12, P_KD_POSTURE = P_KP_POSTURE + 20, P_TAU_MAX = P_KD_POSTURE + 20,
+  P_V_MAX = P_TAU_MAX + 20, P_MAX_ITER = P_V_MAX + 20, P_SIM_ENABLED, P_COUNT = 128
+};
+
+// Model constants in the arithmetic type of the path; one copy in HBM, read by every workgroup
+// (scalar/broadcast loads, L2 resident).
+template <typename T>
+struct DevModel {
+  // ---- TSID side
+  int pin_parent[NJ], pin_depth[NJ], pin_nchild[NJ], pin_child[NJ][MAXCHILD];
+  unsigned pin_anc[NJ]; // bit a set <=> joint a is an ancestor of (or is) joint j
+  int pin_maxdepth;
+  T pin_place[NJ][12];   // R row-major, p
+  T pin_inertia[NJ][10]; // m, c(3), Ixx Ixy Ixz Iyy Iyz Izz about c
+  int frame_parent[2];
+  T frame_place[2][12];
+  T q0[NQ];
+  T mass;
+  // ---- derived from the parameter vector at create / set_params time
+  T params[P_COUNT];
+  T Tgen[6][12];   // contact force generator
+  T Bcone[17][12]; // friction pyramid rows + normal-force row
+  T cone_lb[17], cone_ub[17];
+  T Jf0[12][12];   // L_f^-T of the (constant) force-regularisation Hessian block
+  T Hf_trace, Jf0_trace;
+  // ---- sim side
+  int mj_parent[NB], mj_depth[NB], mj_nchild[NB], mj_child[NB][MAXCHILD];
+  unsigned mj_anc[NB];
+  int mj_maxdepth;
+  T mj_pos[NB][3], mj_R[NB][9]; // body frame in parent (rotation from body_quat)
+  T mj_inertia[NB][10];
+  T mj_armature[NV], mj_frictionloss[NV], mj_dof_invw0[NV], mj_body_invw0[NB][2];
+  int mj_act_dof[NA];
+  T mj_act_kp[NA], mj_act_kv[NA];
+  int mj_ctrl_qidx[NA];
+  int hull_adr[NB + 1];
+  T rbound[NB][4];
+  T opt[7];
+  T contact[8];
+  T meaninertia;
+  const T *hull_vert;  // [nvert][3] body frame (device pointer)
+  const int *hull_eadr, *hull_edge;
+};
+
+// ------------------------------------------------------------------ small vector helpers
+template <typename T> __device__ __forceinline__ void cross3(const T *a, const T *b, T *c) {
+  T x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
+  c[0] = x; c[1] = y; c[2] = z;
+}
+template <typename T> __device__ __forceinline__ T dot3(const T *a, const T *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+template <typename T> __device__ __forceinline__ void mat3vec(const T *R, const T *v, T *o) {
+  T x = R[0] * v[0] + R[1] * v[1] + R[2] * v[2];
+  T y = R[3] * v[0] + R[4] * v[1] + R[5] * v[2];
+  T z = R[6] * v[0] + R[7] * v[1] + R[8] * v[2];
+  o[0] = x; o[1] = y; o[2] = z;
+}
+template <typename T> __device__ __forceinline__ void mat3Tvec(const T *R, const T *v, T *o) {
+  T x = R[0] * v[0] + R[3] * v[1] + R[6] * v[2];
+  T y = R[1] * v[0] + R[4] * v[1] + R[7] * v[2];
+  T z = R[2] * v[0] + R[5] * v[1] + R[8] * v[2];
+  o[0] = x; o[1] = y; o[2] = z;
+}
+template <typename T> __device__ __forceinline__ void mat3mul(const T *A, const T *B, T *C) {
+  T t[9];
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) t[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
+#pragma unroll
+  for (int i = 0; i < 9; i++) C[i] = t[i];
+}
+
+template <typename T> struct Eps;
+template <> struct Eps<double> { static constexpr double v = 2.220446049250313e-16; static constexpr double inf = 1e300; };
+template <> struct Eps<float> { static constexpr float v = 1.1920929e-07f; static constexpr float inf = 1e30f; };
+
+// wavefront reductions over 64 lanes (shuffles; no LDS)
+template <typename T> __device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+  return v;
+}
+template <typename T> __device__ __forceinline__ T wave_min(T v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { T w = __shfl_xor(v, o, WAVE); v = w < v ? w : v; }
+  return v;
+}
+// (value, index) lexicographic minimum: smallest value, lowest index among equals
+template <typename T> __device__ __forceinline__ void wave_argmin(T &v, int &i) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    T w = __shfl_xor(v, o, WAVE);
+    int k = __shfl_xor(i, o, WAVE);
+    if (w < v || (w == v && k < i)) { v = w; i = k; }
+  }
+}
+__device__ __forceinline__ int wave_min_int(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { int w = __shfl_xor(v, o, WAVE); v = w < v ? w : v; }
+  return v;
+}
+
+// quaternion (x,y,z,w order given as separate scalars) -> rotation, normalising
+template <typename T> __device__ __forceinline__ void quat_to_R(T x, T y, T z, T w, T *R) {
+  T n = T(1) / sqrt(x * x + y * y + z * z + w * w);
+  x *= n; y *= n; z *= n; w *= n;
+  R[0] = 1 - 2 * (y * y + z * z); R[1] = 2 * (x * y - w * z); R[2] = 2 * (x * z + w * y);
+  R[3] = 2 * (x * y + w * z); R[4] = 1 - 2 * (x * x + z * z); R[5] = 2 * (y * z - w * x);
+  R[6] = 2 * (x * z - w * y); R[7] = 2 * (y * z + w * x); R[8] = 1 - 2 * (x * x + y * y);
+}
+
+// composite inertia about the reference origin O, world axes: (m, h = m c, I_O sym6)
+// Y * [lin; ang] -> [force; moment]
+template <typename T> __device__ __forceinline__ void yo_mul(const T *Y, const T *X, T *f) {
+  T wxh[3], hxl[3];
+  cross3(X + 3, Y + 1, wxh);
+  cross3(Y + 1, X, hxl);
+  f[0] = Y[0] * X[0] + wxh[0];
+  f[1] = Y[0] * X[1] + wxh[1];
+  f[2] = Y[0] * X[2] + wxh[2];
+  f[3] = Y[4] * X[3] + Y[5] * X[4] + Y[6] * X[5] + hxl[0];
+  f[4] = Y[5] * X[3] + Y[7] * X[4] + Y[8] * X[5] + hxl[1];
+  f[5] = Y[6] * X[3] + Y[8] * X[4] + Y[9] * X[5] + hxl[2];
+}
+// spatial cross products ([lin; ang] about a common origin)
+template <typename T> __device__ __forceinline__ void cross_mm(const T *a, const T *b, T *o) {
+  T t1[3], t2[3], t3[3];
+  cross3(a + 3, b, t1); cross3(a, b + 3, t2); cross3(a + 3, b + 3, t3);
+#pragma unroll
+  for (int i = 0; i < 3; i++) { o[i] = t1[i] + t2[i]; o[3 + i] = t3[i]; }
+}
+template <typename T> __device__ __forceinline__ void cross_mf(const T *v, const T *f, T *o) {
+  T t1[3], t2[3], t3[3];
+  cross3(v + 3, f, t1); cross3(v + 3, f + 3, t2); cross3(v, f, t3);
+#pragma unroll
+  for (int i = 0; i < 3; i++) { o[i] = t1[i]; o[3 + i] = t2[i] + t3[i]; }
+}
+
+// log6 of a relative placement (R row-major, p) -> [v; w]   (pinocchio::log6 semantics)
+template <typename T> __device__ inline void log6(const T *R, const T *p, T *out) {
+  const T PI = T(3.14159265358979323846);
+  T tr = R[0] + R[4] + R[8];
+  T ct = T(0.5) * (tr - 1);
+  ct = ct > 1 ? T(1) : (ct < -1 ? T(-1) : ct);
+  T th = acos(ct);
+  T w[3] = {R[7] - R[5], R[2] - R[6], R[3] - R[1]};
+  T k;
+  const T small = sizeof(T) == 8 ? T(1e-8) : T(1e-4);
+  if (th < small) k = T(0.5) * (1 + th * th / 6);
+  else if (th > PI - T(1e-6) * (sizeof(T) == 8 ? 1 : 1000)) {
+    T ax[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      T d = (R[4 * i] - ct) / (1 - ct);
+      ax[i] = sqrt(d > 0 ? d : T(0));
+      if (w[i] < 0) ax[i] = -ax[i];
+      w[i] = ax[i] * th;
+    }
+    k = 0;
+  } else k = T(0.5) * th / sin(th);
+  if (k != 0) { w[0] *= k; w[1] *= k; w[2] *= k; }
+  T th2 = th * th, beta;
+  if (th < T(1e-4) * (sizeof(T) == 8 ? 1 : 100)) beta = T(1.0 / 12) + th2 / 720;
+  else beta = (1 - th * sin(th) / (2 * (1 - cos(th)))) / th2;
+  T wxp[3], wxwxp[3];
+  cross3(w, p, wxp); cross3(w, wxp, wxwxp);
+#pragma unroll
+  for (int i = 0; i < 3; i++) { out[i] = p[i] - T(0.5) * wxp[i] + beta * wxwxp[i]; out[3 + i] = w[i]; }
+}
+
+} // namespace tsidb

@@ -1,0 +1,646 @@
+// tsidb_sim.hpp - one MuJoCo-subset forward-dynamics + contact step for one env on one wavefront.
+//
+// Replaces, per env, main.py:192-195: base teleport (qpos[:7] = q[:7]), ctrl = map_tsid_to_mujoco(q),
+// mujoco.mj_step.  Feature subset: SURVEY.md 3.4 (free joint + 20 z-hinges, armature, frictionloss,
+// position actuators, floor-plane <-> convex-hull contacts, soft constraints, pyramidal cones,
+// Newton solver with warm start, semi-implicit Euler).
+//
+// MI355X mapping: one wavefront per env, everything in LDS/registers.  Constraint Jacobians are
+// never materialised: a contact row is (direction, point, body), so J x is a body twist evaluated at
+// the point, J^T f is a wrench pushed up the tree, and the Newton Hessian M + J^T D J is the
+// composite-rigid-body recursion run on body inertia plus a per-body 6x6 "contact inertia"
+// sum_rows D w w^T.  The 26x26 factorisations run in registers (lane i = row i, v_readlane).
+// Spatial vectors: [lin; ang], world axes, about the base origin O (z distances use absolute O.z).
+#pragma once
+#include "tsidb_common.hpp"
+#include "tsidb_tick.hpp" // rdlane
+
+namespace tsidb {
+
+constexpr int LDM = 27;
+
+template <typename T>
+struct SimLds {
+  T R[NB][9], p[NB][3];
+  T S[NV][6], V[NB][6], A[NB][6], f[NB][6];
+  T Y[NB][10], Yc[NB][10];
+  T K[NB][21];      // per-body contact inertia (packed sym 6x6), composite after the gather
+  T Wc[MAXCON][21]; // per-contact sum_rows D w w^T
+  T M[NV * LDM], H[NV * LDM];
+  T qpos[NQ], qvel[NV], ctrl[NA];
+  T qfs[NV], qas[NV], qacc[NV], bias[NV], xv[NV], yv[NV];
+  int cbody[MAXCON], cvert[MAXCON];
+  T cr[MAXCON][3], cdist[MAXCON], cfv[MAXCON][3]; // contact point (rel O), distance, force vector
+};
+
+__device__ __forceinline__ int sym_idx(int i, int j) { // packed upper index of a symmetric 6x6
+  const int a = i < j ? i : j, b = i < j ? j : i;
+  return a * 6 - a * (a - 1) / 2 + (b - a);
+}
+
+// Cholesky of the 26x26 SPD matrix whose row `lane` is in a[] (lanes >= 26 hold zeros), then
+// x = A^-1 rhs.  Returns this lane's x; spd=false if a pivot is not positive.
+template <typename T>
+__device__ __forceinline__ T chol26_solve(T (&a)[NV], T rhs, int lane, bool &spd) {
+  spd = true;
+#pragma unroll
+  for (int k = 0; k < NV; k++) {
+    const T akk = rdlane(a[k], k);
+    if (!(akk > 0)) spd = false;
+    const T lkk = sqrt(akk > 0 ? akk : T(1));
+    const T lik = lane == k ? lkk : a[k] / lkk;
+    a[k] = lik;
+#pragma unroll
+    for (int j = k + 1; j < NV; j++) a[j] -= lik * rdlane(lik, j);
+  }
+  T acc = rhs, yv = 0;
+#pragma unroll
+  for (int k = 0; k < NV; k++) {
+    const T yk = rdlane(acc, k) / rdlane(a[k], k);
+    if (lane == k) yv = yk;
+    acc -= a[k] * yk;
+  }
+  T xr[NV], x = 0;
+#pragma unroll
+  for (int i = 0; i < NV; i++) {
+    T sacc = lane == i ? T(1) : T(0);
+#pragma unroll
+    for (int k = 0; k < i; k++) sacc -= rdlane(a[k], i) * xr[k];
+    xr[i] = sacc / rdlane(a[i], i);
+    x += xr[i] * rdlane(yv, i);
+  }
+  return x;
+}
+
+// out = M * x for the lane's dof (x in LDS)
+template <typename T> __device__ __forceinline__ T mulM(const SimLds<T> &L, const T *x, int lane) {
+  T s = 0;
+  if (lane < NV)
+    for (int j = 0; j < NV; j++) s += L.M[lane * LDM + j] * x[j];
+  return s;
+}
+
+// the 4 pyramid rows of contact `c` applied to generalized vector x (LDS): J_row x
+template <typename T>
+__device__ __forceinline__ void contact_rows(const DevModel<T> &m, const SimLds<T> &L, int c, const T *x, T mu, T *out) {
+  T tw[6] = {0, 0, 0, 0, 0, 0};
+  for (int a = L.cbody[c]; a >= 0; a = m.mj_parent[a]) {
+    if (a == 0) {
+      for (int k = 0; k < 6; k++) {
+        const T xk = x[k];
+#pragma unroll
+        for (int i = 0; i < 6; i++) tw[i] += L.S[k][i] * xk;
+      }
+    } else {
+      const T xk = x[5 + a];
+#pragma unroll
+      for (int i = 0; i < 6; i++) tw[i] += L.S[5 + a][i] * xk;
+    }
+  }
+  T wxr[3];
+  cross3(tw + 3, L.cr[c], wxr);
+  // contact frame for the +z floor normal (mju_makeFrame): n = z, t1 = y, t2 = -x
+  const T un = tw[2] + wxr[2], u1 = tw[1] + wxr[1], u2 = -(tw[0] + wxr[0]);
+  out[0] = un + mu * u1; out[1] = un - mu * u1; out[2] = un + mu * u2; out[3] = un - mu * u2;
+}
+
+// per-lane constraint bookkeeping (friction row of dof `lane`, contact `lane`)
+template <typename T>
+struct RowState {
+  // friction dof row
+  bool has_f;
+  T fD, fR, floss, faref, fjar, fJv;
+  // contact rows
+  bool has_c;
+  T cD, caref[4], cjar[4], cJv[4];
+};
+
+// cost / first / second derivative contribution of this lane's rows at jar + alpha*Jv
+template <typename T>
+__device__ __forceinline__ void rows_eval(const RowState<T> &rs, T alpha, T &c, T &g, T &h) {
+  c = 0; g = 0; h = 0;
+  if (rs.has_f) {
+    const T x = rs.fjar + alpha * rs.fJv, f = rs.floss, r = rs.fR;
+    if (x <= -r * f) { c += -T(0.5) * r * f * f - f * x; g += -f * rs.fJv; }
+    else if (x >= r * f) { c += -T(0.5) * r * f * f + f * x; g += f * rs.fJv; }
+    else { c += T(0.5) * rs.fD * x * x; g += rs.fD * x * rs.fJv; h += rs.fD * rs.fJv * rs.fJv; }
+  }
+  if (rs.has_c) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const T x = rs.cjar[i] + alpha * rs.cJv[i];
+      if (x < 0) { c += T(0.5) * rs.cD * x * x; g += rs.cD * x * rs.cJv[i]; h += rs.cD * rs.cJv[i] * rs.cJv[i]; }
+    }
+  }
+}
+
+template <typename T>
+__device__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L, int lane, const T *q_tsid, T *qpos_g, T *qvel_g,
+                             T *qacc_ws_g, T *qacc_out, int *ncon_out, int *con_out, int *info) {
+  const T dt = m.opt[0], gz = m.opt[1], tol = m.opt[2];
+  const int maxiter = (int)m.opt[3], ls_iter = (int)m.opt[4];
+  const T ls_tol = m.opt[5];
+  const T INF = Eps<T>::inf;
+  const T MINVAL = T(1e-15);
+  const bool quirks = m.params[P_QUIRKS] != 0;
+
+  // ---- stage state; teleport the base and map joint targets (main.py:192-194)
+  if (lane < NQ) {
+    T val = qpos_g[lane];
+    if (q_tsid) {
+      if (lane < 3) val = q_tsid[lane];
+      else if (lane < 7) val = quirks ? q_tsid[lane] : (lane == 3 ? q_tsid[6] : q_tsid[lane - 1]);
+    }
+    L.qpos[lane] = val;
+  }
+  if (lane < NV) L.qvel[lane] = qvel_g[lane];
+  if (lane < NA) L.ctrl[lane] = q_tsid ? q_tsid[m.mj_ctrl_qidx[lane]] : T(0);
+  for (int i = lane; i < NV * LDM; i += WAVE) L.M[i] = 0;
+  for (int i = lane; i < NB * 21; i += WAVE) (&L.K[0][0])[i] = 0;
+  __syncthreads();
+  const T Oz = L.qpos[2];
+
+  // ---- kinematics, velocities, bias accelerations, body forces (by tree depth)
+  for (int dpt = 0; dpt <= m.mj_maxdepth; dpt++) {
+    if (lane < NB && m.mj_depth[lane] == dpt) {
+      const int b = lane;
+      T Rb[9], pb[3], Vb[6], Ab[6];
+      if (b == 0) {
+        quat_to_R(L.qpos[4], L.qpos[5], L.qpos[6], L.qpos[3], Rb); // wxyz storage
+        pb[0] = pb[1] = pb[2] = 0;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+#pragma unroll
+          for (int i = 0; i < 3; i++) {
+            L.S[k][i] = (i == k) ? T(1) : T(0); L.S[k][3 + i] = 0;        // world-frame linear dofs
+            L.S[3 + k][i] = 0; L.S[3 + k][3 + i] = Rb[3 * i + k];          // body-frame angular dofs
+          }
+        }
+        T wl[3] = {L.qvel[3], L.qvel[4], L.qvel[5]};
+        Vb[0] = L.qvel[0]; Vb[1] = L.qvel[1]; Vb[2] = L.qvel[2];
+        mat3vec(Rb, wl, Vb + 3);
+        // dS/dt = V x S for the body-fixed angular axes, 0 for the world-fixed linear ones
+#pragma unroll
+        for (int i = 0; i < 6; i++) Ab[i] = 0;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+          T Sk[6] = {0, 0, 0, Rb[k], Rb[3 + k], Rb[6 + k]}, dS[6];
+          cross_mm(Vb, Sk, dS);
+#pragma unroll
+          for (int i = 0; i < 6; i++) Ab[i] += dS[i] * wl[k];
+        }
+      } else {
+        const int p = m.mj_parent[b];
+        T Rq[9], th = L.qpos[6 + b], c = cos(th), s = sin(th);
+        mat3mul(L.R[p], m.mj_R[b], Rq);
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+          Rb[3 * i + 0] = c * Rq[3 * i] + s * Rq[3 * i + 1];
+          Rb[3 * i + 1] = -s * Rq[3 * i] + c * Rq[3 * i + 1];
+          Rb[3 * i + 2] = Rq[3 * i + 2];
+        }
+        mat3vec(L.R[p], m.mj_pos[b], pb);
+#pragma unroll
+        for (int i = 0; i < 3; i++) pb[i] += L.p[p][i];
+        T Sj[6], a[3] = {Rb[2], Rb[5], Rb[8]}, vxs[6];
+        cross3(pb, a, Sj);
+        Sj[3] = a[0]; Sj[4] = a[1]; Sj[5] = a[2];
+        const T qd = L.qvel[5 + b];
+        cross_mm(L.V[p], Sj, vxs);
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+          L.S[5 + b][i] = Sj[i];
+          Vb[i] = L.V[p][i] + Sj[i] * qd;
+          Ab[i] = L.A[p][i] + vxs[i] * qd;
+        }
+      }
+      const T *Yb = m.mj_inertia[b];
+      T cw[3], I[9] = {Yb[4], Yb[5], Yb[6], Yb[5], Yb[7], Yb[8], Yb[6], Yb[8], Yb[9]}, Tm[9], RT[9];
+      mat3vec(Rb, Yb + 1, cw);
+#pragma unroll
+      for (int i = 0; i < 3; i++) cw[i] += pb[i];
+      mat3mul(Rb, I, Tm);
+#pragma unroll
+      for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int k = 0; k < 3; k++) RT[3 * i + k] = Rb[3 * k + i];
+      mat3mul(Tm, RT, I);
+      const T mass = Yb[0], c2 = dot3(cw, cw);
+      T Y[10];
+      Y[0] = mass; Y[1] = mass * cw[0]; Y[2] = mass * cw[1]; Y[3] = mass * cw[2];
+      Y[4] = I[0] + mass * (c2 - cw[0] * cw[0]); Y[5] = I[1] - mass * cw[0] * cw[1]; Y[6] = I[2] - mass * cw[0] * cw[2];
+      Y[7] = I[4] + mass * (c2 - cw[1] * cw[1]); Y[8] = I[5] - mass * cw[1] * cw[2];
+      Y[9] = I[8] + mass * (c2 - cw[2] * cw[2]);
+      T Ag[6] = {Ab[0], Ab[1], Ab[2] - gz, Ab[3], Ab[4], Ab[5]}, Ya[6], Yv[6], vx[6];
+      yo_mul(Y, Ag, Ya);
+      yo_mul(Y, Vb, Yv);
+      cross_mf(Vb, Yv, vx);
+#pragma unroll
+      for (int i = 0; i < 9; i++) L.R[b][i] = Rb[i];
+#pragma unroll
+      for (int i = 0; i < 3; i++) L.p[b][i] = pb[i];
+#pragma unroll
+      for (int i = 0; i < 6; i++) { L.V[b][i] = Vb[i]; L.A[b][i] = Ab[i]; L.f[b][i] = Ya[i] + vx[i]; }
+#pragma unroll
+      for (int i = 0; i < 10; i++) { L.Y[b][i] = Y[i]; L.Yc[b][i] = Y[i]; }
+    }
+    __syncthreads();
+  }
+  for (int dpt = m.mj_maxdepth - 1; dpt >= 0; dpt--) {
+    if (lane < NB && m.mj_depth[lane] == dpt) {
+      const int b = lane;
+      for (int ci = 0; ci < m.mj_nchild[b]; ci++) {
+        const int c = m.mj_child[b][ci];
+#pragma unroll
+        for (int i = 0; i < 6; i++) L.f[b][i] += L.f[c][i];
+#pragma unroll
+        for (int i = 0; i < 10; i++) L.Yc[b][i] += L.Yc[c][i];
+      }
+    }
+    __syncthreads();
+  }
+  // ---- per dof: bias, mass-matrix column (+ armature), actuation
+  T qfs = 0;
+  if (lane < NV) {
+    const int k = lane, bk = k < 6 ? 0 : k - 5;
+    T Sk[6], Fk[6], hk = 0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) { Sk[i] = L.S[k][i]; hk += Sk[i] * L.f[bk][i]; }
+    L.bias[k] = hk;
+    yo_mul(L.Yc[bk], Sk, Fk);
+    int a = bk;
+    while (true) {
+      if (a == 0) {
+        for (int i = 0; i < 6 && i <= k; i++) {
+          T val = 0;
+#pragma unroll
+          for (int e = 0; e < 6; e++) val += L.S[i][e] * Fk[e];
+          L.M[i * LDM + k] = val;
+          L.M[k * LDM + i] = val;
+        }
+        break;
+      }
+      const int i = 5 + a;
+      T val = 0;
+#pragma unroll
+      for (int e = 0; e < 6; e++) val += L.S[i][e] * Fk[e];
+      L.M[i * LDM + k] = val;
+      L.M[k * LDM + i] = val;
+      a = m.mj_parent[a];
+    }
+    qfs = -hk;
+  }
+  __syncthreads();
+  if (lane < NV) L.M[lane * LDM + lane] += m.mj_armature[lane];
+  if (lane < NA) {
+    const int d = m.mj_act_dof[lane];
+    L.xv[d] = m.mj_act_kp[lane] * (L.ctrl[lane] - L.qpos[d + 1]) - m.mj_act_kv[lane] * L.qvel[d];
+  } else if (lane >= 32 && lane < 38) L.xv[lane - 32] = 0;
+  __syncthreads();
+  if (lane < NV) { qfs += L.xv[lane]; L.qfs[lane] = qfs; }
+  // ---- qacc_smooth = M^-1 qfrc_smooth
+  T arow[NV];
+#pragma unroll
+  for (int j = 0; j < NV; j++) arow[j] = lane < NV ? L.M[lane * LDM + j] : T(0);
+  bool spd;
+  const T qas = chol26_solve(arow, qfs, lane, spd);
+  int fail = spd ? 0 : 1;
+  if (lane < NV) L.qas[lane] = qas;
+
+  // ---- collision: floor plane (z = 0, normal +z) against each body's convex hull
+  const T margin = 0, tie_tol = m.opt[6];
+  int ncon = 0;
+  for (int b = 0; b < NB && ncon < MAXCON; b++) {
+    const T *Rb = L.R[b];
+    const T pz = L.p[b][2] + Oz;
+    const T zc = Rb[6] * m.rbound[b][0] + Rb[7] * m.rbound[b][1] + Rb[8] * m.rbound[b][2] + pz;
+    if (zc - m.rbound[b][3] > margin) continue;
+    const int v0 = m.hull_adr[b], v1 = m.hull_adr[b + 1];
+    const T r6 = Rb[6], r7 = Rb[7], r8 = Rb[8];
+    T zmin = INF;
+    for (int i = v0 + lane; i < v1; i += WAVE) {
+      const T *vv = m.hull_vert + 3 * i;
+      const T z = r6 * vv[0] + r7 * vv[1] + r8 * vv[2] + pz;
+      zmin = z < zmin ? z : zmin;
+    }
+    zmin = wave_min(zmin);
+    if (zmin > margin) continue;
+    int best = 0x7fffffff;
+    for (int i = v0 + lane; i < v1 && best == 0x7fffffff; i += WAVE) {
+      const T *vv = m.hull_vert + 3 * i;
+      const T z = r6 * vv[0] + r7 * vv[1] + r8 * vv[2] + pz;
+      if (z <= zmin + tie_tol) best = i;
+    }
+    best = wave_min_int(best);
+    const int e0 = m.hull_eadr[best];
+    int nnb = m.hull_eadr[best + 1] - e0;
+    nnb = nnb > WAVE - 1 ? WAVE - 1 : nnb;
+    bool keep = false;
+    T w[3] = {0, 0, 0};
+    int vid = best;
+    if (lane <= nnb) {
+      if (lane > 0) vid = v0 + m.hull_edge[e0 + lane - 1];
+      const T *vv = m.hull_vert + 3 * vid;
+      mat3vec(Rb, vv, w);
+      w[0] += L.p[b][0]; w[1] += L.p[b][1]; w[2] += pz;
+      keep = lane == 0 || w[2] <= margin;
+    }
+    const unsigned long long mask = __ballot(keep);
+    const int slot = ncon + __popcll(mask & ((1ull << lane) - 1ull));
+    if (keep && slot < MAXCON) {
+      const T dist = w[2];
+      L.cbody[slot] = b;
+      L.cvert[slot] = vid - v0;
+      L.cdist[slot] = dist;
+      L.cr[slot][0] = w[0]; L.cr[slot][1] = w[1]; L.cr[slot][2] = w[2] - T(0.5) * dist - Oz;
+    }
+    ncon += __popcll(mask);
+    ncon = ncon > MAXCON ? MAXCON : ncon;
+  }
+  __syncthreads();
+  if (lane == 0 && ncon_out) ncon_out[0] = ncon;
+  if (con_out && lane < MAXCON) con_out[lane] = lane < ncon ? ((L.cbody[lane] << 16) | L.cvert[lane]) : -1;
+
+  // ---- constraint rows: frictionloss (lane = dof), pyramidal contact rows (lane = contact)
+  const T mu = m.contact[0];
+  const T timeconst = m.contact[1] > 2 * dt ? m.contact[1] : 2 * dt, dampratio = m.contact[2];
+  const T dmin = m.contact[3], dmax = m.contact[4], width = m.contact[5], mid = m.contact[6], power = m.contact[7];
+  const T kk = T(1) / (dmax * dmax * timeconst * timeconst * dampratio * dampratio), bb = T(2) / (dmax * timeconst);
+  RowState<T> rs;
+  rs.has_f = lane < NV && m.mj_frictionloss[lane < NV ? lane : 0] > 0;
+  rs.fD = rs.fR = rs.floss = rs.faref = rs.fjar = rs.fJv = 0;
+  if (rs.has_f) {
+    const T r = (1 - dmin) / dmin * m.mj_dof_invw0[lane];
+    rs.fR = r > MINVAL ? r : MINVAL;
+    rs.fD = T(1) / rs.fR;
+    rs.floss = m.mj_frictionloss[lane];
+    rs.faref = -bb * L.qvel[lane];
+  }
+  rs.has_c = lane < ncon;
+  rs.cD = 0;
+#pragma unroll
+  for (int i = 0; i < 4; i++) rs.caref[i] = rs.cjar[i] = rs.cJv[i] = 0;
+  if (rs.has_c) {
+    const int c = lane;
+    const T dist = L.cdist[c];
+    T x = fabs(dist - margin) / width, imp;
+    if (x >= 1) imp = dmax;
+    else if (x <= 0) imp = dmin;
+    else {
+      T y;
+      if (x <= mid) y = pow(x, power) / pow(mid, power - 1);
+      else y = 1 - pow(1 - x, power) / pow(1 - mid, power - 1);
+      imp = dmin + y * (dmax - dmin);
+    }
+    const T tran = m.mj_body_invw0[L.cbody[c]][0];
+    const T diagA = tran + mu * mu * tran;
+    T R0 = (1 - imp) / imp * diagA;
+    R0 = R0 > MINVAL ? R0 : MINVAL;
+    rs.cD = T(1) / (2 * mu * mu * R0);
+    T vel[4];
+    contact_rows(m, L, c, L.qvel, mu, vel);
+#pragma unroll
+    for (int i = 0; i < 4; i++) rs.caref[i] = -bb * vel[i] - kk * imp * (dist - margin);
+  }
+
+  int solver_iter = 0;
+  T qacc = qas;
+  const int nefc = 20 + 4 * ncon; // frictionloss rows exist on all 20 hinges
+  if (nefc > 0) {
+    // helpers over a candidate qacc held per lane (value `xa`, also staged in L.xv)
+    auto stage = [&](T xa) { __syncthreads(); if (lane < NV) L.xv[lane] = xa; __syncthreads(); };
+    auto jar_of = [&](T xa) { // fills rs.fjar / rs.cjar from L.xv
+      if (rs.has_f) rs.fjar = xa - rs.faref;
+      if (rs.has_c) {
+        T o[4];
+        contact_rows(m, L, lane, L.xv, mu, o);
+#pragma unroll
+        for (int i = 0; i < 4; i++) rs.cjar[i] = o[i] - rs.caref[i];
+      }
+    };
+    // warm start: keep qacc_warmstart only if it is cheaper than qacc_smooth
+    T xw = lane < NV ? qacc_ws_g[lane] : T(0);
+    stage(xw);
+    T Ma = mulM(L, L.xv, lane);
+    jar_of(xw);
+    T cc, gg, hh;
+    rows_eval(rs, T(0), cc, gg, hh);
+    T cost_w = wave_sum(cc + (lane < NV ? T(0.5) * (Ma - qfs) * (xw - qas) : T(0)));
+    stage(qas);
+    jar_of(qas);
+    rows_eval(rs, T(0), cc, gg, hh);
+    T cost_s = wave_sum(cc);
+    if (cost_w > cost_s) { qacc = qas; }
+    else { qacc = xw; }
+    stage(qacc);
+    Ma = mulM(L, L.xv, lane);
+    jar_of(qacc);
+
+    const T scale = T(1) / (m.meaninertia * NV);
+    T cost = 0;
+    int iter = 0;
+    while (true) {
+      // ---- constraint state at the current point: forces, active rows, cost
+      rows_eval(rs, T(0), cc, gg, hh);
+      const T gauss = wave_sum(lane < NV ? T(0.5) * (Ma - qfs) * (qacc - qas) : T(0));
+      const T newcost = gauss + wave_sum(cc);
+      // force on the friction row and force vector of the contact
+      T ff = 0;
+      bool fact = false;
+      if (rs.has_f) {
+        const T f = rs.floss, r = rs.fR;
+        if (rs.fjar <= -r * f) ff = f;
+        else if (rs.fjar >= r * f) ff = -f;
+        else { ff = -rs.fD * rs.fjar; fact = true; }
+      }
+      T Arow[6] = {0, 0, 0, 0, 0, 0}; // sum_rows D dir dir^T (sym 3x3: xx xy xz yy yz zz)
+      if (rs.has_c) {
+        T fr[4];
+        T fv[3] = {0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const bool act = rs.cjar[i] < 0;
+          fr[i] = act ? -rs.cD * rs.cjar[i] : T(0);
+          // direction of row i in world axes: n + s*mu*t, n = z, t1 = y, t2 = -x
+          const T sg = (i & 1) ? -mu : mu;
+          const T dir[3] = {i >= 2 ? -sg : T(0), i < 2 ? sg : T(0), T(1)};
+#pragma unroll
+          for (int e = 0; e < 3; e++) fv[e] += fr[i] * dir[e];
+          if (act) {
+            Arow[0] += rs.cD * dir[0] * dir[0]; Arow[1] += rs.cD * dir[0] * dir[1]; Arow[2] += rs.cD * dir[0] * dir[2];
+            Arow[3] += rs.cD * dir[1] * dir[1]; Arow[4] += rs.cD * dir[1] * dir[2]; Arow[5] += rs.cD * dir[2] * dir[2];
+          }
+        }
+        L.cfv[lane][0] = fv[0]; L.cfv[lane][1] = fv[1]; L.cfv[lane][2] = fv[2];
+      }
+      __syncthreads();
+      // ---- gradient: Ma - qfrc_smooth - J^T force
+      T grad = 0;
+      if (lane < NV) {
+        const int k = lane, bk = k < 6 ? 0 : k - 5;
+        T s = 0;
+        for (int c = 0; c < ncon; c++) {
+          if (!((m.mj_anc[L.cbody[c]] >> bk) & 1u)) continue;
+          T rxf[3];
+          cross3(L.cr[c], L.cfv[c], rxf);
+          s += L.S[k][0] * L.cfv[c][0] + L.S[k][1] * L.cfv[c][1] + L.S[k][2] * L.cfv[c][2] +
+               L.S[k][3] * rxf[0] + L.S[k][4] * rxf[1] + L.S[k][5] * rxf[2];
+        }
+        grad = Ma - qfs - s - ff;
+      }
+      if (iter > 0) {
+        const T gn = wave_sum(grad * grad);
+        const T improvement = scale * (cost - newcost), gradient = scale * sqrt(gn);
+        cost = newcost;
+        if (improvement < tol || gradient < tol) break;
+      }
+      cost = newcost;
+      if (iter >= maxiter) break;
+      // ---- Newton Hessian H = M + J^T D J: CRB recursion on the per-body contact inertia
+      if (rs.has_c) {
+        // W = [A, -A [r]x ; [r]x A, -[r]x A [r]x] with [r]x the cross matrix of the contact point
+        const T *r = L.cr[lane];
+        const T A3[9] = {Arow[0], Arow[1], Arow[2], Arow[1], Arow[3], Arow[4], Arow[2], Arow[4], Arow[5]};
+        const T X[9] = {0, -r[2], r[1], r[2], 0, -r[0], -r[1], r[0], 0};
+        T XA[9], XAXt[9], Xt[9];
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+          for (int j = 0; j < 3; j++) Xt[3 * i + j] = X[3 * j + i];
+        mat3mul(X, A3, XA);
+        mat3mul(XA, Xt, XAXt);
+        // upper-left A, upper-right (X A)^T, lower-right X A X^T
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+          for (int j = i; j < 3; j++) { L.Wc[lane][sym_idx(i, j)] = A3[3 * i + j]; L.Wc[lane][sym_idx(3 + i, 3 + j)] = XAXt[3 * i + j]; }
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+          for (int j = 0; j < 3; j++) L.Wc[lane][sym_idx(i, 3 + j)] = XA[3 * j + i];
+      }
+      __syncthreads();
+      for (int idx = lane; idx < NB * 21; idx += WAVE) {
+        const int b = idx / 21, e = idx % 21;
+        T s = 0;
+        for (int c = 0; c < ncon; c++)
+          if (L.cbody[c] == b) s += L.Wc[c][e];
+        L.K[b][e] = s;
+      }
+      __syncthreads();
+      for (int dpt = m.mj_maxdepth - 1; dpt >= 0; dpt--) {
+        if (lane < NB && m.mj_depth[lane] == dpt)
+          for (int ci = 0; ci < m.mj_nchild[lane]; ci++) {
+            const int c = m.mj_child[lane][ci];
+            for (int e = 0; e < 21; e++) L.K[lane][e] += L.K[c][e];
+          }
+        __syncthreads();
+      }
+      for (int i = lane; i < NV * LDM; i += WAVE) L.H[i] = L.M[i];
+      __syncthreads();
+      if (lane < NV) {
+        const int k = lane, bk = k < 6 ? 0 : k - 5;
+        T G[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+          T s = 0;
+#pragma unroll
+          for (int j = 0; j < 6; j++) s += L.K[bk][sym_idx(i, j)] * L.S[k][j];
+          G[i] = s;
+        }
+        int a = bk;
+        while (true) {
+          const int i0 = a == 0 ? 0 : 5 + a, i1 = a == 0 ? 5 : 5 + a;
+          for (int i = i0; i <= i1 && i <= k; i++) {
+            T val = 0;
+#pragma unroll
+            for (int e = 0; e < 6; e++) val += L.S[i][e] * G[e];
+            L.H[i * LDM + k] += val;
+            if (i != k) L.H[k * LDM + i] += val;
+          }
+          if (a == 0) break;
+          a = m.mj_parent[a];
+        }
+        if (fact) L.H[k * LDM + k] += rs.fD;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < NV; j++) arow[j] = lane < NV ? L.H[lane * LDM + j] : T(0);
+      bool ok;
+      const T search = -chol26_solve(arow, grad, lane, ok);
+      if (!ok) { fail |= 2; break; }
+      // ---- exact line search along `search`
+      stage(search);
+      const T Mv = mulM(L, L.xv, lane);
+      if (rs.has_f) rs.fJv = search;
+      if (rs.has_c) contact_rows(m, L, lane, L.xv, mu, rs.cJv);
+      T qg1 = wave_sum(lane < NV ? search * (Ma - qfs) : T(0));
+      T qg2 = wave_sum(lane < NV ? T(0.5) * search * Mv : T(0));
+      T snorm = sqrt(wave_sum(lane < NV ? search * search : T(0)));
+      if (snorm < MINVAL) break;
+      const T gtol = tol * ls_tol * snorm * m.meaninertia * NV;
+      auto ls_eval = [&](T alpha, T &c, T &d1, T &d2) {
+        T lc, lg, lh;
+        rows_eval(rs, alpha, lc, lg, lh);
+        c = alpha * alpha * qg2 + alpha * qg1 + gauss + wave_sum(lc);
+        d1 = 2 * alpha * qg2 + qg1 + wave_sum(lg);
+        d2 = 2 * qg2 + wave_sum(lh);
+      };
+      T c0, g1, g2, ca, alpha = 0, lo = 0, hi = INF;
+      ls_eval(T(0), c0, g1, g2);
+      ca = c0;
+      for (int li = 0; li < ls_iter && fabs(g1) >= gtol; li++) {
+        if (g1 < 0) lo = alpha; else hi = alpha;
+        T an = alpha - g1 / g2;
+        if (!(an > lo) || !(an < hi)) an = hi >= INF ? 2 * alpha + 1 : T(0.5) * (lo + hi);
+        alpha = an;
+        ls_eval(alpha, ca, g1, g2);
+      }
+      if (!(ca < c0) || alpha == 0) break;
+      qacc += alpha * search;
+      Ma += alpha * Mv;
+      if (rs.has_f) rs.fjar += alpha * rs.fJv;
+      if (rs.has_c) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) rs.cjar[i] += alpha * rs.cJv[i];
+      }
+      iter++;
+    }
+    solver_iter = iter;
+  }
+  __syncthreads();
+  // ---- semi-implicit Euler, write back
+  if (lane < NV) {
+    const T vn = L.qvel[lane] + dt * qacc;
+    L.qvel[lane] = vn;
+    qvel_g[lane] = vn;
+    qacc_ws_g[lane] = qacc;
+    if (qacc_out) qacc_out[lane] = qacc;
+  }
+  __syncthreads();
+  if (lane < 3) L.qpos[lane] += dt * L.qvel[lane];
+  if (lane >= 6 && lane < NV) L.qpos[lane + 1] += dt * L.qvel[lane];
+  if (lane == 3) {
+    const T *w = &L.qvel[3];
+    const T th = sqrt(dot3(w, w)) * dt;
+    T dq[4] = {1, 0, 0, 0};
+    if (th > 0) {
+      const T s = sin(T(0.5) * th) * dt / th;
+      dq[0] = cos(T(0.5) * th); dq[1] = s * w[0]; dq[2] = s * w[1]; dq[3] = s * w[2];
+    }
+    const T a[4] = {L.qpos[3], L.qpos[4], L.qpos[5], L.qpos[6]};
+    T r[4];
+    r[0] = a[0] * dq[0] - a[1] * dq[1] - a[2] * dq[2] - a[3] * dq[3];
+    r[1] = a[0] * dq[1] + a[1] * dq[0] + a[2] * dq[3] - a[3] * dq[2];
+    r[2] = a[0] * dq[2] - a[1] * dq[3] + a[2] * dq[0] + a[3] * dq[1];
+    r[3] = a[0] * dq[3] + a[1] * dq[2] - a[2] * dq[1] + a[3] * dq[0];
+    const T nn = T(1) / sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3]);
+#pragma unroll
+    for (int i = 0; i < 4; i++) L.qpos[3 + i] = r[i] * nn;
+  }
+  __syncthreads();
+  if (lane < NQ) qpos_g[lane] = L.qpos[lane];
+  if (lane == 0 && info) { info[2] = solver_iter; info[3] = fail; }
+}
+
+} // namespace tsidb

@@ -1,0 +1,854 @@
+// tsidb_tick.hpp - one TSID tick for one env on one 64-lane wavefront.
+//
+// Replaces, per env, the reference's per-tick calls (main.py:119-129):
+//   formulation.computeProblemData -> rbd_terms() + assemble()      (tsid / pinocchio)
+//   solver.solve                    -> qp_solve()                     (tsid SolverHQuadProgFast / eiquadprog)
+//   getActuatorForces / getAccelerations / integrate_dv / get_cop    -> finish()
+//
+// MI355X mapping: the env's whole problem lives in LDS + registers of one wavefront; HBM traffic is
+// the state/refs in and state/outputs out.  Rigid-body terms use world-aligned spatial vectors about
+// the base origin (no per-joint frame changes; keeps magnitudes < 0.5 m for fp32).  The 26x26
+// Hessian block is assembled, Cholesky-factorised and inverted entirely in registers with
+// v_readlane broadcasts (lane i owns row i); the force blocks' factor is a model constant.  The
+// dual active-set iterations keep J (50x51) and packed R in LDS; constraint adds use one Householder
+// reflection instead of eiquadprog's Givens chain (same iterates, no sequential sqrt/div chain).
+#pragma once
+#include "tsidb_common.hpp"
+
+namespace tsidb {
+
+template <typename T>
+struct KinScratch { // aliased onto the J factor's LDS; dead before the QP starts
+  T R[NJ][9], p[NJ][3], S[NV][6], V[NJ][6], A[NJ][6], f[NJ][6], Yc[NJ][10], F[NV][6];
+  T fR[2][9], fp[2][3];
+};
+
+template <typename T>
+struct TickLds {
+  union {
+    T J[NVAR * LDJ];
+    KinScratch<T> k;
+  };
+  T R[NVAR * (NVAR + 1) / 2 + 1];
+  T Dyn[NV * LDD]; // row r = [M[r][0:26] | -Jc[:, r]^T]  (rows 0..5: base dynamics, 6..25: actuation)
+  T Jf[12 * LDF];  // frame Jacobians, LOCAL (LF rows 0..5, RF rows 6..11)
+  T Jcom[3 * LDF];
+  T h[NV];
+  T x[NVAR], g[NVAR], d[NVAR], z[NVAR], r[NVAR + 2], np[NVAR], u[NVAR + 2], xold[NVAR], uold[NVAR + 2];
+  T s[160];
+  T arhs[4][6]; // a_des - drift: contact LF, contact RF, foot LF, foot RF
+  T acomr[3], apost[NA];
+  T oMf[2][12]; // frame placement: R row-major, p (world)
+  T vf[2][6], af[2][6];
+  T com[3], vcom[3], acomd[3];
+  T qs[NQ], vs[NV];
+  int A[NVAR + 2], Aold[NVAR + 2];
+  unsigned char cstate[160]; // bit0: in the active set, bit1: excluded for this outer iteration
+};
+
+template <typename T> __device__ __forceinline__ T bcast(T v, int src) { return __shfl(v, src, WAVE); }
+
+// lane-uniform readlane for float / double (src must be wave-uniform; constant after unrolling)
+__device__ __forceinline__ float rdlane(float v, int src) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src));
+}
+__device__ __forceinline__ double rdlane(double v, int src) {
+  long long b = __builtin_bit_cast(long long, v);
+  int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffLL), src);
+  int hi = __builtin_amdgcn_readlane((int)(b >> 32), src);
+  return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+
+// --------------------------------------------------------------------------- rigid-body terms
+// Inputs L.qs, L.vs.  Outputs: L.Dyn (M part, rest zero), L.h, L.Jf, L.Jcom, L.oMf, L.vf, L.af,
+// L.com, L.vcom, L.acomd.  Spatial vectors are [lin; ang] in world axes about the base origin O.
+template <typename T>
+__device__ void rbd_terms(const DevModel<T> &m, TickLds<T> &L, int lane) {
+  KinScratch<T> &K = L.k;
+  const T GZ = T(9.81);
+  for (int i = lane; i < NV * LDD; i += WAVE) L.Dyn[i] = 0;
+  // ---- forward pass by tree depth
+  for (int dpt = 0; dpt <= m.pin_maxdepth; dpt++) {
+    if (lane < NJ && m.pin_depth[lane] == dpt) {
+      const int j = lane;
+      T Rj[9], pj[3], Vj[6], Aj[6];
+      if (j == 0) {
+        quat_to_R(L.qs[3], L.qs[4], L.qs[5], L.qs[6], Rj);
+        pj[0] = pj[1] = pj[2] = 0;
+        mat3vec(Rj, &L.vs[0], Vj);
+        mat3vec(Rj, &L.vs[3], Vj + 3);
+#pragma unroll
+        for (int i = 0; i < 6; i++) Aj[i] = 0;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+#pragma unroll
+          for (int i = 0; i < 3; i++) {
+            K.S[k][i] = Rj[3 * i + k]; K.S[k][3 + i] = 0;
+            K.S[3 + k][i] = 0; K.S[3 + k][3 + i] = Rj[3 * i + k];
+          }
+        }
+      } else {
+        const int p = m.pin_parent[j];
+        const T *PR = m.pin_place[j];
+        T th = L.qs[6 + j], c = cos(th), s = sin(th), Rl[9];
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+          Rl[3 * i + 0] = c * PR[3 * i] + s * PR[3 * i + 1];
+          Rl[3 * i + 1] = -s * PR[3 * i] + c * PR[3 * i + 1];
+          Rl[3 * i + 2] = PR[3 * i + 2];
+        }
+        mat3mul(K.R[p], Rl, Rj);
+        mat3vec(K.R[p], PR + 9, pj);
+#pragma unroll
+        for (int i = 0; i < 3; i++) pj[i] += K.p[p][i];
+        T Sj[6], a[3] = {Rj[2], Rj[5], Rj[8]};
+        cross3(pj, a, Sj);
+        Sj[3] = a[0]; Sj[4] = a[1]; Sj[5] = a[2];
+        T qd = L.vs[5 + j], vxs[6];
+        cross_mm(K.V[p], Sj, vxs);
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+          K.S[5 + j][i] = Sj[i];
+          Vj[i] = K.V[p][i] + Sj[i] * qd;
+          Aj[i] = K.A[p][i] + vxs[i] * qd;
+        }
+      }
+      // body inertia about O in world axes, RNEA body force (gravity as +g base acceleration)
+      const T *Yb = m.pin_inertia[j];
+      T cw[3], I[9] = {Yb[4], Yb[5], Yb[6], Yb[5], Yb[7], Yb[8], Yb[6], Yb[8], Yb[9]}, Tm[9], RT[9];
+      mat3vec(Rj, Yb + 1, cw);
+#pragma unroll
+      for (int i = 0; i < 3; i++) cw[i] += pj[i];
+      mat3mul(Rj, I, Tm);
+#pragma unroll
+      for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int k = 0; k < 3; k++) RT[3 * i + k] = Rj[3 * k + i];
+      mat3mul(Tm, RT, I);
+      T mass = Yb[0], c2 = dot3(cw, cw), Y[10];
+      Y[0] = mass; Y[1] = mass * cw[0]; Y[2] = mass * cw[1]; Y[3] = mass * cw[2];
+      Y[4] = I[0] + mass * (c2 - cw[0] * cw[0]); Y[5] = I[1] - mass * cw[0] * cw[1]; Y[6] = I[2] - mass * cw[0] * cw[2];
+      Y[7] = I[4] + mass * (c2 - cw[1] * cw[1]); Y[8] = I[5] - mass * cw[1] * cw[2];
+      Y[9] = I[8] + mass * (c2 - cw[2] * cw[2]);
+      T Ag[6] = {Aj[0], Aj[1], Aj[2] + GZ, Aj[3], Aj[4], Aj[5]}, Ya[6], Yv[6], vx[6];
+      yo_mul(Y, Ag, Ya);
+      yo_mul(Y, Vj, Yv);
+      cross_mf(Vj, Yv, vx);
+#pragma unroll
+      for (int i = 0; i < 9; i++) K.R[j][i] = Rj[i];
+#pragma unroll
+      for (int i = 0; i < 3; i++) K.p[j][i] = pj[i];
+#pragma unroll
+      for (int i = 0; i < 6; i++) { K.V[j][i] = Vj[i]; K.A[j][i] = Aj[i]; K.f[j][i] = Ya[i] + vx[i]; }
+#pragma unroll
+      for (int i = 0; i < 10; i++) K.Yc[j][i] = Y[i];
+    }
+    __syncthreads();
+  }
+  // ---- backward gather by depth: subtree forces and composite inertias
+  for (int dpt = m.pin_maxdepth - 1; dpt >= 0; dpt--) {
+    if (lane < NJ && m.pin_depth[lane] == dpt) {
+      const int j = lane;
+      for (int ci = 0; ci < m.pin_nchild[j]; ci++) {
+        const int c = m.pin_child[j][ci];
+#pragma unroll
+        for (int i = 0; i < 6; i++) K.f[j][i] += K.f[c][i];
+#pragma unroll
+        for (int i = 0; i < 10; i++) K.Yc[j][i] += K.Yc[c][i];
+      }
+    }
+    __syncthreads();
+  }
+  // ---- per dof: bias, F = Yc S, mass-matrix entries, CoM Jacobian column
+  const T invm = T(1) / m.mass;
+  if (lane < NV) {
+    const int k = lane, jk = k < 6 ? 0 : k - 5;
+    T Sk[6], Fk[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) Sk[i] = K.S[k][i];
+    T hk = 0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) hk += Sk[i] * K.f[jk][i];
+    L.h[k] = hk;
+    yo_mul(K.Yc[jk], Sk, Fk);
+#pragma unroll
+    for (int i = 0; i < 6; i++) K.F[k][i] = Fk[i];
+    L.Jcom[0 * LDF + k] = Fk[0] * invm;
+    L.Jcom[1 * LDF + k] = Fk[1] * invm;
+    L.Jcom[2 * LDF + k] = Fk[2] * invm;
+    int a = jk;
+    while (true) {
+      if (a == 0) {
+        for (int i = 0; i < 6 && i <= k; i++) {
+          T val = 0;
+#pragma unroll
+          for (int e = 0; e < 6; e++) val += K.S[i][e] * Fk[e];
+          L.Dyn[i * LDD + k] = val;
+          L.Dyn[k * LDD + i] = val;
+        }
+        break;
+      }
+      const int i = 5 + a;
+      T val = 0;
+#pragma unroll
+      for (int e = 0; e < 6; e++) val += K.S[i][e] * Fk[e];
+      L.Dyn[i * LDD + k] = val;
+      L.Dyn[k * LDD + i] = val;
+      a = m.pin_parent[a];
+    }
+  }
+  // ---- frames (lanes 0,1): placement, velocity, classical drift acceleration (LOCAL)
+  if (lane < 2) {
+    const int f = lane, jf = m.frame_parent[f];
+    const T *P = m.frame_place[f];
+    T Rf[9], pf[3];
+    mat3mul(K.R[jf], P, Rf);
+    mat3vec(K.R[jf], P + 9, pf);
+#pragma unroll
+    for (int i = 0; i < 3; i++) pf[i] += K.p[jf][i];
+    const T *V = K.V[jf], *A = K.A[jf];
+    T wxp[3], vP[3], axp[3], wxv[3], aP[3];
+    cross3(V + 3, pf, wxp);
+#pragma unroll
+    for (int i = 0; i < 3; i++) vP[i] = V[i] + wxp[i];
+    cross3(A + 3, pf, axp);
+    cross3(V + 3, vP, wxv);
+#pragma unroll
+    for (int i = 0; i < 3; i++) aP[i] = A[i] + axp[i] + wxv[i];
+    mat3Tvec(Rf, vP, L.vf[f]);
+    mat3Tvec(Rf, V + 3, L.vf[f] + 3);
+    mat3Tvec(Rf, aP, L.af[f]);
+    mat3Tvec(Rf, A + 3, L.af[f] + 3);
+#pragma unroll
+    for (int i = 0; i < 9; i++) { L.oMf[f][i] = Rf[i]; K.fR[f][i] = Rf[i]; }
+#pragma unroll
+    for (int i = 0; i < 3; i++) { L.oMf[f][9 + i] = pf[i] + L.qs[i]; K.fp[f][i] = pf[i]; }
+  }
+  if (lane == 2) {
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      L.com[i] = K.Yc[0][1 + i] * invm + L.qs[i];
+      L.acomd[i] = K.f[0][i] * invm - (i == 2 ? GZ : T(0));
+    }
+  }
+  __syncthreads();
+  // ---- frame Jacobian columns (LOCAL) and CoM velocity
+  if (lane < NV) {
+    const int k = lane, jk = k < 6 ? 0 : k - 5;
+#pragma unroll
+    for (int f = 0; f < 2; f++) {
+      T col[6] = {0, 0, 0, 0, 0, 0};
+      if ((m.pin_anc[m.frame_parent[f]] >> jk) & 1u) {
+        T wxp[3], lin[3];
+        cross3(&K.S[k][3], K.fp[f], wxp);
+#pragma unroll
+        for (int i = 0; i < 3; i++) lin[i] = K.S[k][i] + wxp[i];
+        mat3Tvec(K.fR[f], lin, col);
+        mat3Tvec(K.fR[f], &K.S[k][3], col + 3);
+      }
+#pragma unroll
+      for (int i = 0; i < 6; i++) L.Jf[(6 * f + i) * LDF + k] = col[i];
+    }
+  }
+  {
+    T vk = lane < NV ? L.vs[lane] : T(0);
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      T part = lane < NV ? L.Jcom[i * LDF + lane] * vk : T(0);
+      T tot = wave_sum(part);
+      if (lane == 0) L.vcom[i] = tot;
+    }
+  }
+  __syncthreads();
+}
+
+// --------------------------------------------------------------------------- task right-hand sides
+// TaskSE3Equality in the local frame: kp*log6(M^-1 Mref) + kd*(R^T vref - v) + R^T aref - drift
+template <typename T>
+__device__ void se3_rhs(const TickLds<T> &L, int f, const T *ref, int nref, T kp, T kd, T *rhs) {
+  const T *R = L.oMf[f], *p = L.oMf[f] + 9;
+  T rel[9], d[3], pr[3], err[6];
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      T s = 0;
+#pragma unroll
+      for (int k = 0; k < 3; k++) s += R[3 * k + i] * ref[3 + 3 * j + k]; // ref rotation is column-major
+      rel[3 * i + j] = s;
+    }
+#pragma unroll
+  for (int i = 0; i < 3; i++) d[i] = ref[i] - p[i];
+  mat3Tvec(R, d, pr);
+  log6(rel, pr, err);
+#pragma unroll
+  for (int h = 0; h < 2; h++) {
+    T vr[3] = {0, 0, 0}, ar[3] = {0, 0, 0};
+    if (nref >= 24) {
+      mat3Tvec(R, ref + 12 + 3 * h, vr);
+      mat3Tvec(R, ref + 18 + 3 * h, ar);
+    }
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+      rhs[3 * h + i] = kp * err[3 * h + i] + kd * (vr[i] - L.vf[f][3 * h + i]) + ar[i] - L.af[f][3 * h + i];
+  }
+}
+
+// --------------------------------------------------------------------------- QP pieces
+__device__ __forceinline__ int rcol(int c) { return c * (c + 1) / 2; } // packed upper-triangular column start
+
+template <typename T>
+struct QpCtx {
+  int n, nslot, nin, p, iq;
+  int slot_foot[2];
+  T R_norm;
+};
+
+// value of one-sided inequality row r at L.x  (CI x + ci0), rows ordered as tsid stacks them
+template <typename T>
+__device__ T row_value(const DevModel<T> &m, const TickLds<T> &L, const QpCtx<T> &c, int r) {
+  const int nc = 34 * c.nslot;
+  if (r < nc) {
+    const int s = r / 34, rr = r % 34, up = rr >= 17, b = rr % 17;
+    const T *xf = &L.x[NV + 12 * s];
+    T val = 0;
+    if (b < 16) {
+      const int pt = b >> 2;
+#pragma unroll
+      for (int e = 0; e < 3; e++) val += m.Bcone[b][3 * pt + e] * xf[3 * pt + e];
+    } else {
+      for (int e = 0; e < 12; e++) val += m.Bcone[16][e] * xf[e];
+    }
+    return up ? m.cone_ub[b] - val : val - m.cone_lb[b];
+  }
+  r -= nc;
+  if (r < 2 * NA) {
+    const int up = r >= NA, j = r % NA;
+    T val = 0;
+    for (int e = 0; e < c.n; e++) val += L.Dyn[(6 + j) * LDD + e] * L.x[e];
+    const T tm = m.params[P_TAU_MAX + j], hj = L.h[6 + j];
+    return up ? (tm - hj) - val : val - (-tm - hj);
+  }
+  r -= 2 * NA;
+  const int up = r >= NV, k = r % NV;
+  T lo = T(-1e10), hi = T(1e10);
+  if (k >= 6) {
+    const T dt2 = 2 * m.params[P_DT], vmax = m.params[P_V_MAX + k - 6], vk = L.vs[k];
+    T amax = (vmax - vk) / dt2, amin = (-vmax - vk) / dt2;
+    hi = amax < T(1e10) ? amax : T(1e10);
+    lo = amin > T(-1e10) ? amin : T(-1e10);
+  }
+  return up ? hi - L.x[k] : L.x[k] - lo;
+}
+
+// materialise the normal of inequality row r into L.np and return its nonzero range
+template <typename T>
+__device__ void row_fill(const DevModel<T> &m, TickLds<T> &L, const QpCtx<T> &c, int r, int lane, int &i0, int &i1) {
+  const int nc = 34 * c.nslot;
+  T val = 0;
+  if (r < nc) {
+    const int s = r / 34, rr = r % 34, up = rr >= 17, b = rr % 17;
+    i0 = NV + 12 * s; i1 = i0 + 12;
+    if (lane >= i0 && lane < i1) val = up ? -m.Bcone[b][lane - i0] : m.Bcone[b][lane - i0];
+  } else if (r < nc + 2 * NA) {
+    const int a = r - nc, up = a >= NA, j = a % NA;
+    i0 = 0; i1 = c.n;
+    if (lane < c.n) val = up ? -L.Dyn[(6 + j) * LDD + lane] : L.Dyn[(6 + j) * LDD + lane];
+  } else {
+    const int b = r - nc - 2 * NA, up = b >= NV, k = b % NV;
+    i0 = k; i1 = k + 1;
+    if (lane == k) val = up ? T(-1) : T(1);
+  }
+  if (lane < c.n) L.np[lane] = val;
+  __syncthreads();
+}
+
+// d = J^T np ; Householder the tail d[iq:] onto d[iq] (rotating J's free columns) ; z = J[:,iq] d[iq] ;
+// r = R^-1 d[:iq].  Returns z.z and z.np.
+template <typename T>
+__device__ void step_direction(TickLds<T> &L, QpCtx<T> &c, int lane, int i0, int i1, T &zz, T &znp) {
+  const int n = c.n, iq = c.iq;
+  if (lane < n) {
+    T acc = 0;
+    for (int i = i0; i < i1; i++) acc += L.J[i * LDJ + lane] * L.np[i];
+    L.d[lane] = acc;
+  }
+  __syncthreads();
+  zz = 0; znp = 0;
+  if (iq < n) {
+    T dj = (lane > iq && lane < n) ? L.d[lane] : T(0);
+    T sigma = wave_sum(dj * dj);
+    T alpha = L.d[iq];
+    if (sigma > 0) {
+      T nrm = sqrt(alpha * alpha + sigma);
+      T v0 = alpha + (alpha >= 0 ? nrm : -nrm);
+      T beta = T(2) / (v0 * v0 + sigma);
+      if (lane == iq) L.z[iq] = v0;
+      else if (lane > iq && lane < n) L.z[lane] = dj;
+      __syncthreads();
+      if (lane < n) {
+        T w = 0;
+        for (int j = iq; j < n; j++) w += L.J[lane * LDJ + j] * L.z[j];
+        w *= beta;
+        for (int j = iq; j < n; j++) L.J[lane * LDJ + j] -= w * L.z[j];
+      }
+      if (lane == iq) L.d[iq] = alpha >= 0 ? -nrm : nrm;
+      else if (lane > iq && lane < n) L.d[lane] = 0;
+      __syncthreads();
+    }
+    const T diq = L.d[iq];
+    T zi = 0;
+    if (lane < n) { zi = L.J[lane * LDJ + iq] * diq; }
+    zz = wave_sum(zi * zi);
+    znp = diq * diq;
+    __syncthreads();
+    if (lane < n) L.z[lane] = zi;
+  } else {
+    if (lane < n) L.z[lane] = 0;
+  }
+  // r = R^-1 d[:iq], column-oriented back substitution on packed R
+  T rl = lane < iq ? L.d[lane] : T(0);
+  for (int j = iq - 1; j >= 0; j--) {
+    const T rj = bcast(rl, j) / L.R[rcol(j) + j];
+    if (lane == j) rl = rj;
+    else if (lane < j) rl -= L.R[rcol(j) + lane] * rj;
+  }
+  if (lane < iq) L.r[lane] = rl;
+  __syncthreads();
+}
+
+// append the current direction as active constraint column iq; false if numerically dependent
+template <typename T>
+__device__ bool add_constraint(TickLds<T> &L, QpCtx<T> &c, int lane) {
+  const int iq = c.iq;
+  if (iq >= c.n) return false;
+  if (lane <= iq) L.R[rcol(iq) + lane] = L.d[lane];
+  const T dd = fabs(L.d[iq]);
+  c.iq = iq + 1;
+  __syncthreads();
+  if (dd <= Eps<T>::v * c.R_norm) return false;
+  if (dd > c.R_norm) c.R_norm = dd;
+  return true;
+}
+
+// remove active constraint l (an inequality index) from the working set
+template <typename T>
+__device__ void delete_constraint(TickLds<T> &L, QpCtx<T> &c, int lane, int l) {
+  const int n = c.n;
+  int iq = c.iq;
+  int cand = (lane >= c.p && lane < iq && L.A[lane] == l) ? lane : 9999;
+  const int qq = wave_min_int(cand);
+  if (qq >= iq) return;
+  // Givens sweep: old column j+1 becomes column j, rotations act on rows (j, j+1)
+  for (int j = qq; j < iq - 1; j++) {
+    const int co = j + 1;
+    T cc = L.R[rcol(co) + j], ss = L.R[rcol(co) + j + 1];
+    T h = hypot(cc, ss);
+    if (h == 0) continue;
+    cc /= h; ss /= h;
+    T diag = h;
+    if (cc < 0) { cc = -cc; ss = -ss; diag = -h; }
+    const T xny = ss / (T(1) + cc);
+    __syncthreads();
+    for (int k = co + 1 + lane; k < iq; k += WAVE) {
+      T t1 = L.R[rcol(k) + j], t2 = L.R[rcol(k) + j + 1];
+      T n1 = t1 * cc + t2 * ss;
+      L.R[rcol(k) + j] = n1;
+      L.R[rcol(k) + j + 1] = xny * (t1 + n1) - t2;
+    }
+    if (lane == 0) { L.R[rcol(co) + j] = diag; L.R[rcol(co) + j + 1] = 0; }
+    if (lane < n) {
+      T t1 = L.J[lane * LDJ + j], t2 = L.J[lane * LDJ + j + 1];
+      T n1 = t1 * cc + t2 * ss;
+      L.J[lane * LDJ + j] = n1;
+      L.J[lane * LDJ + j + 1] = xny * (n1 + t1) - t2;
+    }
+    __syncthreads();
+  }
+  // shift packed columns left (sequential over columns, lanes over rows)
+  for (int k = qq + 1; k < iq; k++) {
+    T val = lane < k ? L.R[rcol(k) + lane] : T(0);
+    __syncthreads();
+    if (lane < k) L.R[rcol(k - 1) + lane] = val;
+    __syncthreads();
+  }
+  // shift A and u (slot iq holds the candidate and moves down too)
+  int Av = 0;
+  T uv = 0;
+  if (lane >= qq && lane < iq) { Av = L.A[lane + 1]; uv = L.u[lane + 1]; }
+  __syncthreads();
+  if (lane >= qq && lane < iq) { L.A[lane] = Av; L.u[lane] = uv; }
+  if (lane == 0) { L.A[iq] = 0; L.u[iq] = 0; }
+  c.iq = iq - 1;
+  __syncthreads();
+}
+
+// Goldfarb-Idnani dual active set over the LDS-resident problem.  On entry L.J = L^-T, L.x = -H^-1 g.
+template <typename T>
+__device__ int qp_solve(const DevModel<T> &m, TickLds<T> &L, QpCtx<T> &c, int lane, T c1, T c2, int max_iter, int &iter_out) {
+  const int n = c.n;
+  c.iq = 0;
+  c.R_norm = 1;
+  const T INF = Eps<T>::inf;
+  // ---------------- equality constraints
+  for (int i = 0; i < c.p; i++) {
+    T ce0;
+    int i0 = 0, i1 = n;
+    T val = 0;
+    if (i < 6) {
+      if (lane < n) val = L.Dyn[i * LDD + lane];
+      ce0 = L.h[i];
+    } else {
+      const int s = (i - 6) / 6, rr = (i - 6) % 6, f = c.slot_foot[s];
+      if (lane < NV) val = L.Jf[(6 * f + rr) * LDF + lane];
+      ce0 = -L.arhs[f][rr];
+      i1 = NV;
+    }
+    if (lane < n) L.np[lane] = val;
+    __syncthreads();
+    T zz, znp;
+    step_direction(L, c, lane, i0, i1, zz, znp);
+    T npx = wave_sum(lane < n ? val * L.x[lane] : T(0));
+    T t2 = 0;
+    if (fabs(zz) > Eps<T>::v) t2 = (-npx - ce0) / znp;
+    if (lane < n) L.x[lane] += t2 * L.z[lane];
+    if (lane < c.iq) L.u[lane] -= t2 * L.r[lane];
+    if (lane == 0) { L.u[c.iq] = t2; L.A[i] = -i - 1; }
+    __syncthreads();
+    if (!add_constraint(L, c, lane)) { iter_out = 0; return 4; }
+  }
+  for (int r = lane; r < c.nin; r += WAVE) L.cstate[r] = 0;
+  __syncthreads();
+
+  int iter = 0, status = -1;
+  while (status < 0) {
+    // ---------------- l1: new outer iteration
+    iter++;
+    if (iter >= max_iter) { status = 3; break; }
+    T psi = 0;
+    for (int r = lane; r < c.nin; r += WAVE) {
+      T sv = row_value(m, L, c, r);
+      L.s[r] = sv;
+      L.cstate[r] &= 1; // clear exclusion marks
+      psi += sv < 0 ? sv : T(0);
+    }
+    psi = wave_sum(psi);
+    if (fabs(psi) <= T(c.nin) * Eps<T>::v * c1 * c2 * T(100)) { status = 0; break; }
+    if (lane < n) L.xold[lane] = L.x[lane];
+    if (lane < c.iq) { L.uold[lane] = L.u[lane]; L.Aold[lane] = L.A[lane]; }
+    const int iq_old = c.iq;
+    __syncthreads();
+
+    bool outer_done = false;
+    while (!outer_done && status < 0) {
+      // ---------------- l2: most violated eligible constraint (lowest index among equals)
+      T best = 0;
+      int ip = 0x7fffffff;
+      for (int r = lane; r < c.nin; r += WAVE) {
+        T sv = L.s[r];
+        if (L.cstate[r] == 0 && sv < best) { best = sv; ip = r; }
+      }
+      wave_argmin(best, ip);
+      if (!(best < 0)) { status = 0; break; }
+      int i0, i1;
+      row_fill(m, L, c, ip, lane, i0, i1);
+      if (lane == 0) { L.u[c.iq] = 0; L.A[c.iq] = ip; }
+      __syncthreads();
+
+      while (true) {
+        // ---------------- l2a: step direction and lengths
+        T zz, znp;
+        step_direction(L, c, lane, i0, i1, zz, znp);
+        T t1 = INF;
+        int kmin = 0x7fffffff;
+        if (lane >= c.p && lane < c.iq) {
+          T rk = L.r[lane];
+          if (rk > 0) { t1 = L.u[lane] / rk; kmin = lane; }
+        }
+        wave_argmin(t1, kmin);
+        const int l = kmin < c.iq ? L.A[kmin] : 0;
+        const T sip = L.s[ip];
+        const T t2 = fabs(zz) > Eps<T>::v ? -sip / znp : INF;
+        const T t = t1 < t2 ? t1 : t2;
+        if (t >= INF) { status = 1; break; }
+        if (t2 >= INF) { // dual step only
+          if (lane < c.iq) L.u[lane] -= t * L.r[lane];
+          if (lane == 0) L.u[c.iq] += t;
+          if (lane == 0) L.cstate[l] &= ~1;
+          __syncthreads();
+          delete_constraint(L, c, lane, l);
+          continue;
+        }
+        if (lane < n) L.x[lane] += t * L.z[lane];
+        if (lane < c.iq) L.u[lane] -= t * L.r[lane];
+        if (lane == 0) L.u[c.iq] += t;
+        __syncthreads();
+        if (t == t2) { // full step: ip joins the active set
+          if (!add_constraint(L, c, lane)) {
+            if (lane == 0) L.cstate[ip] |= 2;
+            __syncthreads();
+            delete_constraint(L, c, lane, ip);
+            // restore the state saved at l1
+            for (int r = lane; r < c.nin; r += WAVE) L.cstate[r] &= 2;
+            __syncthreads();
+            if (lane < c.iq) {
+              L.A[lane] = L.Aold[lane]; L.u[lane] = L.uold[lane];
+              if (lane >= c.p) L.cstate[L.Aold[lane]] |= 1;
+            }
+            if (lane < n) L.x[lane] = L.xold[lane];
+            __syncthreads();
+            (void)iq_old;
+            break; // back to l2
+          }
+          if (lane == 0) L.cstate[ip] |= 1;
+          __syncthreads();
+          outer_done = true;
+          break; // back to l1
+        }
+        // partial step: drop l, refresh s[ip], recompute direction
+        if (lane == 0) L.cstate[l] &= ~1;
+        __syncthreads();
+        delete_constraint(L, c, lane, l);
+        T sv = row_value(m, L, c, ip);
+        if (lane == 0) L.s[ip] = sv;
+        __syncthreads();
+      }
+    }
+  }
+  iter_out = iter;
+  return status;
+}
+
+// --------------------------------------------------------------------------- the tick
+template <typename T>
+__device__ void tsid_tick_env(const DevModel<T> &m, TickLds<T> &L, int lane, T *q, T *v, const T *com_ref,
+                              const T *posture_ref, const T *foot_ref, const T *contact_ref,
+                              const uint8_t *cact, const T *cop_frames, T *tau, T *dv, T *fout, int *status_out,
+                              T *obs, int *info) {
+  // ---- stage state
+  if (lane < NQ) L.qs[lane] = q[lane];
+  if (lane < NV) L.vs[lane] = v[lane];
+  __syncthreads();
+  rbd_terms(m, L, lane);
+
+  QpCtx<T> c;
+  c.nslot = 0;
+  c.slot_foot[0] = c.slot_foot[1] = -1;
+  const int act0 = cact[0] != 0, act1 = cact[1] != 0;
+  if (act0) c.slot_foot[c.nslot++] = 0;
+  if (act1) c.slot_foot[c.nslot++] = 1;
+  c.n = NV + 12 * c.nslot;
+  c.p = 6 + 6 * c.nslot;
+  c.nin = 34 * c.nslot + 2 * NA + 2 * NV;
+  const int n = c.n;
+
+  // ---- task right-hand sides
+  if (lane < 2) se3_rhs(L, lane, contact_ref + 12 * lane, 12, m.params[P_KP_CONTACT], m.params[P_KD_CONTACT], L.arhs[lane]);
+  else if (lane < 4) se3_rhs(L, lane - 2, foot_ref + 24 * (lane - 2), 24, m.params[P_KP_FOOT], m.params[P_KD_FOOT], L.arhs[lane]);
+  else if (lane < 7) {
+    const int i = lane - 4;
+    L.acomr[i] = -m.params[P_KP_COM] * (L.com[i] - com_ref[i]) - m.params[P_KD_COM] * (L.vcom[i] - com_ref[3 + i]) +
+                 com_ref[6 + i] - L.acomd[i];
+  } else if (lane >= 32 && lane < 32 + NA) {
+    const int r = lane - 32;
+    L.apost[r] = -m.params[P_KP_POSTURE + r] * (L.qs[7 + r] - posture_ref[r]) - m.params[P_KD_POSTURE + r] * L.vs[6 + r];
+  }
+  // ---- right block of the dynamics rows: Dyn[r][26 + 12 s + cc] = -sum_i T[i][cc] Jf[6 f + i][r]
+  for (int idx = lane; idx < NV * 12 * c.nslot; idx += WAVE) {
+    const int r = idx / (12 * c.nslot), cc = idx % (12 * c.nslot), s = cc / 12, e = cc % 12, f = c.slot_foot[s];
+    T a = 0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) a += m.Tgen[i][e] * L.Jf[(6 * f + i) * LDF + r];
+    L.Dyn[r * LDD + NV + cc] = -a;
+  }
+  __syncthreads(); // kinematics scratch is dead from here on
+
+  // ---- Hessian block of dv in registers: lane i owns row i
+  const T w_foot = m.params[P_W_FOOT], w_com = m.params[P_W_COM], w_post = m.params[P_W_POSTURE], reg = m.params[P_HESS_REG];
+  T jt[15], a[NV];
+  {
+    const int i = lane < NV ? lane : 0;
+#pragma unroll
+    for (int r = 0; r < 12; r++) jt[r] = lane < NV ? L.Jf[r * LDF + i] : T(0);
+#pragma unroll
+    for (int r = 0; r < 3; r++) jt[12 + r] = lane < NV ? L.Jcom[r * LDF + i] : T(0);
+  }
+  T gi = 0;
+#pragma unroll
+  for (int r = 0; r < 12; r++) gi -= w_foot * jt[r] * L.arhs[2 + r / 6][r % 6];
+#pragma unroll
+  for (int r = 0; r < 3; r++) gi -= w_com * jt[12 + r] * L.acomr[r];
+  if (lane >= 6 && lane < NV) gi -= w_post * L.apost[lane - 6];
+  if (lane >= NV) gi = 0;
+#pragma unroll
+  for (int j = 0; j < NV; j++) {
+    T acc = 0;
+#pragma unroll
+    for (int r = 0; r < 12; r++) acc += w_foot * jt[r] * rdlane(jt[r], j);
+#pragma unroll
+    for (int r = 0; r < 3; r++) acc += w_com * jt[12 + r] * rdlane(jt[12 + r], j);
+    a[j] = acc;
+  }
+#pragma unroll
+  for (int j = 0; j < NV; j++)
+    if (lane == j) a[j] += reg + (j >= 6 ? w_post : T(0));
+  T c1 = 0;
+#pragma unroll
+  for (int j = 0; j < NV; j++) c1 += rdlane(a[j], j);
+  c1 += T(c.nslot) * m.Hf_trace;
+
+  // ---- Cholesky in registers (right-looking; lane i holds row i of L in a[0..i])
+  bool spd = true;
+#pragma unroll
+  for (int k = 0; k < NV; k++) {
+    const T akk = rdlane(a[k], k);
+    if (!(akk > 0)) spd = false;
+    const T lkk = sqrt(akk > 0 ? akk : T(1));
+    const T lik = lane == k ? lkk : a[k] / lkk;
+    a[k] = lik;
+#pragma unroll
+    for (int j = k + 1; j < NV; j++) a[j] -= lik * rdlane(lik, j);
+  }
+  // ---- y = L^-1 (-g) by forward substitution, X = L^-1 column per lane (= row of L^-T)
+  T acc = -gi, yv = 0;
+#pragma unroll
+  for (int k = 0; k < NV; k++) {
+    const T yk = rdlane(acc, k) / rdlane(a[k], k);
+    if (lane == k) yv = yk;
+    acc -= a[k] * yk;
+  }
+  T xr[NV]; // xr[i] = X[i][lane] = (L^-1)[i][lane] = (L^-T)[lane][i]
+#pragma unroll
+  for (int i = 0; i < NV; i++) {
+    T sacc = lane == i ? T(1) : T(0);
+#pragma unroll
+    for (int k = 0; k < i; k++) sacc -= rdlane(a[k], i) * xr[k];
+    xr[i] = sacc / rdlane(a[i], i);
+  }
+  // x0 = L^-T y : row `lane` of L^-T dotted with y
+  T x0 = 0, c2 = 0;
+#pragma unroll
+  for (int i = 0; i < NV; i++) {
+    x0 += xr[i] * rdlane(yv, i);
+    c2 += rdlane(xr[i], i);
+  }
+  c2 += T(c.nslot) * m.Jf0_trace;
+  // ---- write J = L^-T (block diagonal) and x0, g to LDS
+  for (int i = lane; i < NVAR * LDJ; i += WAVE) L.J[i] = 0;
+  __syncthreads();
+  if (lane < NV) {
+#pragma unroll
+    for (int i = 0; i < NV; i++)
+      if (i >= lane) L.J[lane * LDJ + i] = xr[i];
+  } else if (lane < n) {
+    const int e = (lane - NV) % 12, off = NV + 12 * ((lane - NV) / 12);
+    for (int b = e; b < 12; b++) L.J[lane * LDJ + off + b] = m.Jf0[e][b];
+  }
+  if (lane < n) { L.x[lane] = lane < NV ? x0 : T(0); L.g[lane] = gi; }
+  if (lane < NVAR + 2) { L.u[lane] = 0; L.A[lane] = 0; }
+  __syncthreads();
+
+  int iters = 0;
+  int status = spd ? qp_solve(m, L, c, lane, c1, c2, (int)m.params[P_MAX_ITER], iters) : 2;
+
+  // ---- decode: dv, f, tau = M_a dv + h_a - J_a^T f
+  if (lane < NV) dv[lane] = L.x[lane];
+  if (lane < 24) {
+    const int fo = lane / 12, e = lane % 12;
+    T val = 0;
+    for (int s = 0; s < c.nslot; s++)
+      if (c.slot_foot[s] == fo) val = L.x[NV + 12 * s + e];
+    fout[lane] = val;
+    L.s[lane] = val; // staged for the CoP
+  }
+  if (lane < NA) {
+    T t = L.h[6 + lane];
+    for (int e = 0; e < n; e++) t += L.Dyn[(6 + lane) * LDD + e] * L.x[e];
+    tau[lane] = t;
+  }
+  if (lane == 0) {
+    status_out[0] = status;
+    if (info) { info[0] = iters; info[1] = c.iq; }
+  }
+  __syncthreads();
+  // ---- observations from this tick's data (main.py:132-142 reads data() before recomputing)
+  if (obs) {
+    if (lane == 0) {
+      T fz[2], copw[2][3];
+#pragma unroll
+      for (int fo = 0; fo < 2; fo++) {
+        T w[6] = {0, 0, 0, 0, 0, 0};
+        for (int e = 0; e < 12; e++) {
+          T fe = L.s[12 * fo + e];
+#pragma unroll
+          for (int i = 0; i < 6; i++) w[i] += m.Tgen[i][e] * fe;
+        }
+        T cl[3] = {0, 0, 0};
+        const bool on = fo == 0 ? act0 : act1;
+        if (on && w[2] > T(1e-3)) { cl[0] = w[4] / w[2]; cl[1] = w[3] / w[2]; }
+        const T *F = (m.params[P_QUIRKS] != 0 && cop_frames) ? cop_frames + 12 * fo : L.oMf[fo];
+#pragma unroll
+        for (int i = 0; i < 3; i++) copw[fo][i] = F[3 * i] * cl[0] + F[3 * i + 1] * cl[1] + F[3 * i + 2] * cl[2] + F[9 + i];
+        fz[fo] = w[2];
+      }
+      T cop[3] = {0, 0, 0};
+      if (act0 && act1 && fz[0] + fz[1] != 0) {
+        cop[0] = (copw[0][0] * fz[0] + copw[1][0] * fz[1]) / (fz[0] + fz[1]);
+        cop[1] = (copw[0][1] * fz[0] + copw[1][1] * fz[1]) / (fz[0] + fz[1]);
+      }
+#pragma unroll
+      for (int i = 0; i < 3; i++) obs[56 + i] = cop[i];
+    }
+    if (lane >= 8 && lane < 11) obs[53 + lane - 8] = L.com[lane - 8];
+    if (lane >= 16 && lane < 19) obs[59 + lane - 16] = L.oMf[0][9 + lane - 16];
+    if (lane >= 24 && lane < 27) obs[62 + lane - 24] = L.oMf[1][9 + lane - 24];
+  }
+  // ---- integrate_dv (WalkController.py:291-295); a failed QP leaves the state untouched
+  if (status == 0) {
+    const T dt = m.params[P_DT];
+    T vm = 0;
+    if (lane < NV) {
+      const T vv = L.vs[lane], dd = L.x[lane];
+      vm = dt * (vv + T(0.5) * dt * dd);
+      L.vs[lane] = vv + dt * dd;
+      L.d[lane] = vm;
+    }
+    __syncthreads();
+    if (lane >= 6 && lane < NV) L.qs[lane + 1] += vm;
+    if (lane == 0) {
+      const T *vl = &L.d[0], *w = &L.d[3];
+      const T th2 = dot3(w, w), th = sqrt(th2);
+      const T small = sizeof(T) == 8 ? T(1e-8) : T(1e-4);
+      T b, cc, sh, ch;
+      if (th < small) { b = T(0.5) - th2 / 24; cc = T(1.0 / 6) - th2 / 120; sh = T(0.5) - th2 / 48; ch = 1 - th2 / 8; }
+      else { b = (1 - cos(th)) / th2; cc = (th - sin(th)) / (th2 * th); sh = sin(T(0.5) * th) / th; ch = cos(T(0.5) * th); }
+      T wxv[3], wxwxv[3], pd[3], R0[9], rp[3];
+      cross3(w, vl, wxv); cross3(w, wxv, wxwxv);
+#pragma unroll
+      for (int i = 0; i < 3; i++) pd[i] = vl[i] + b * wxv[i] + cc * wxwxv[i];
+      quat_to_R(L.qs[3], L.qs[4], L.qs[5], L.qs[6], R0);
+      mat3vec(R0, pd, rp);
+      const T dq[4] = {sh * w[0], sh * w[1], sh * w[2], ch};
+      const T aq[4] = {L.qs[3], L.qs[4], L.qs[5], L.qs[6]};
+      T r[4];
+      r[0] = aq[3] * dq[0] + aq[0] * dq[3] + aq[1] * dq[2] - aq[2] * dq[1];
+      r[1] = aq[3] * dq[1] - aq[0] * dq[2] + aq[1] * dq[3] + aq[2] * dq[0];
+      r[2] = aq[3] * dq[2] + aq[0] * dq[1] - aq[1] * dq[0] + aq[2] * dq[3];
+      r[3] = aq[3] * dq[3] - aq[0] * dq[0] - aq[1] * dq[1] - aq[2] * dq[2];
+      const T nn = T(1) / sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3]);
+#pragma unroll
+      for (int i = 0; i < 3; i++) L.qs[i] += rp[i];
+#pragma unroll
+      for (int i = 0; i < 4; i++) L.qs[3 + i] = r[i] * nn;
+    }
+    __syncthreads();
+    if (lane < NQ) q[lane] = L.qs[lane];
+    if (lane < NV) v[lane] = L.vs[lane];
+  }
+  if (obs) {
+    if (lane < NQ) obs[lane] = L.qs[lane];
+    if (lane < NV) obs[NQ + lane] = L.vs[lane];
+  }
+}
+
+} // namespace tsidb

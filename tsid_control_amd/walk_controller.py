@@ -1,0 +1,273 @@
+"""WalkController - batched, MI355X-resident counterpart of the reference's ctrl/WalkController.py.
+
+Same constructor argument (a RobotConfig), same attribute and method names
+(ctrl/WalkController.py:11-295), but every quantity carries a leading env axis and lives in a
+torch-ROCm tensor that the HIP kernels update in place through the C-ABI (include/tsidb.h).
+`reset()` and `step()` are new: they encapsulate WalkController.py:22-26,72-79 + main.py:57-64 and
+main.py:119-129,192-195 respectively (the reference writes that loop inline).
+
+The task stack (what the reference builds with tsid calls at WalkController.py:54-187) is fixed
+inside the kernels: 2x Contact6d (hard), 2x TaskSE3Equality, TaskComEquality, TaskJointPosture,
+TaskActuationBounds, TaskJointBounds, SolverHQuadProgFast.  The `formulation`, `solver`, `robot`
+objects of the reference have no counterpart - their work happens inside `step()`.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from .conf import RobotConfig
+from .model import ModelBlob
+from .params import P_COUNT, pack_params
+
+NQ, NV, NA, NOBS, MAXCON = 27, 26, 20, 65, 32
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+class TrajectorySample:
+    """Minimal stand-in for tsid.TrajectorySample for SE3 tasks: pos [N,12] (p, R column-major),
+    vel [N,6], acc [N,6] (WalkController.py:195-196 passes such samples to setReference)."""
+
+    def __init__(self, pos, vel=None, acc=None):
+        self.pos = pos
+        self.vel = vel if vel is not None else torch.zeros(pos.shape[0], 6, dtype=pos.dtype, device=pos.device)
+        self.acc = acc if acc is not None else torch.zeros(pos.shape[0], 6, dtype=pos.dtype, device=pos.device)
+
+
+class WalkController:
+    def __init__(self, conf: RobotConfig = None, num_envs: int = None, device=None):
+        self.conf = conf = conf if conf is not None else RobotConfig()
+        self.num_envs = N = int(num_envs if num_envs is not None else getattr(conf, "num_envs", 1))
+        self.device = torch.device(device if device is not None else getattr(conf, "device", "cuda"))
+        if self.device.type != "cuda":
+            raise _lib.TsidbError("WalkController needs a ROCm device: the hot path has no CPU implementation")
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        dt_name = getattr(conf, "dtype", "f64")
+        self.dtype = {"f64": torch.float64, "f32": torch.float32}[dt_name]
+        self.model = ModelBlob(getattr(conf, "model_blob", None))
+        self.params = pack_params(conf, self.model.effort_limit, self.model.velocity_limit)
+        self._L = L = _lib.load()
+        self._h = C.c_void_p()
+        raw = self.model.raw
+        rc = L.tsidb_create(raw, len(raw), self.params.ctypes.data_as(C.c_void_p), P_COUNT, N, self.device.index,
+                            0 if dt_name == "f64" else 1, C.byref(self._h))
+        _lib.check(L, self._h, rc, "tsidb_create")
+
+        z = lambda *s, dt=self.dtype: torch.zeros(*s, dtype=dt, device=self.device)
+        # TSID state (WalkController.py:23-24) and sim state (main.py:51,64)
+        self.q, self.v = z(N, NQ), z(N, NV)
+        self.qpos, self.qvel, self.qacc_warmstart = z(N, NQ), z(N, NV), z(N, NV)
+        # task references
+        self.com_ref, self.posture_ref = z(N, 9), z(N, NA)
+        self.foot_ref, self.contact_ref, self.cop_frames = z(N, 2, 24), z(N, 2, 12), z(N, 2, 12)
+        self.contact_active = torch.ones(N, 2, dtype=torch.uint8, device=self.device)
+        # outputs
+        self.tau, self.dv, self.f = z(N, NA), z(N, NV), z(N, 24)
+        self.status = z(N, dt=torch.int32)
+        self.obs, self.frames = z(N, NOBS), z(N, 2, 12)
+        self.ncon, self.con_pairs = z(N, dt=torch.int32), z(N, MAXCON, dt=torch.int32)
+        self.info = z(N, 4, dt=torch.int32)
+        rc = L.tsidb_set_refs(self._h, _ptr(self.com_ref), _ptr(self.posture_ref), _ptr(self.foot_ref),
+                              _ptr(self.contact_ref), _ptr(self.contact_active), _ptr(self.cop_frames))
+        _lib.check(L, self._h, rc, "tsidb_set_refs")
+
+        # WalkController.py:168-169,179-180
+        self.tau_max = conf.tau_max_scaling * self.model.effort_limit
+        self.tau_min = -self.tau_max
+        self.v_max = conf.v_max_scaling * self.model.velocity_limit
+        self.v_min = -self.v_max
+        self.LF_frame, self.RF_frame = 0, 1
+        self.t = 0.0
+        self.reset()
+        self.q0 = self.q.clone()  # WalkController.py:23 (after the z shift of :74, which aliases q0)
+
+    def __del__(self):
+        try:
+            if self._h:
+                self._L.tsidb_destroy(self._h)
+                self._h = C.c_void_p()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ helpers
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    @property
+    def contactLF_active(self):
+        return self.contact_active[:, 0].bool()
+
+    @property
+    def contactRF_active(self):
+        return self.contact_active[:, 1].bool()
+
+    def set_params(self):
+        """Re-read self.conf (edited RobotConfig values) into the device-side constants."""
+        self.params = pack_params(self.conf, self.model.effort_limit, self.model.velocity_limit)
+        rc = self._L.tsidb_set_params(self._h, self.params.ctypes.data_as(C.c_void_p), P_COUNT)
+        _lib.check(self._L, self._h, rc, "tsidb_set_params")
+
+    # ------------------------------------------------------------------ reset / step
+    def reset(self, env_ids=None):
+        """Standing state with the soles on z = 0 and all references re-captured
+        (WalkController.py:22-26,72-79,81,122,151-152,164-165; main.py:57-64)."""
+        ids = None
+        n_ids = 0
+        if env_ids is not None:
+            ids = torch.as_tensor(env_ids, dtype=torch.int32, device=self.device).contiguous()
+            n_ids = ids.numel()
+        with torch.cuda.device(self.device):
+            rc = self._L.tsidb_reset(self._h, _ptr(ids), n_ids, _ptr(self.q), _ptr(self.v), _ptr(self.qpos),
+                                     _ptr(self.qvel), _ptr(self.qacc_warmstart), self._stream())
+        _lib.check(self._L, self._h, rc, "tsidb_reset")
+        if env_ids is None:
+            self.frames.copy_(self.cop_frames)
+            self.t = 0.0
+        else:
+            self.frames[ids.long()] = self.cop_frames[ids.long()]
+
+    def step(self, n_substeps: int = 1):
+        """One env step for every env: TSID tick (main.py:119-129) then, if conf.sim_enabled, base
+        teleport + joint targets + sim step (main.py:192-195).  Returns (tau, q, v, status, obs);
+        all are views of the controller's tensors, updated in place."""
+        with torch.cuda.device(self.device):
+            rc = self._L.tsidb_step(self._h, _ptr(self.q), _ptr(self.v), _ptr(self.qpos), _ptr(self.qvel),
+                                    _ptr(self.qacc_warmstart), _ptr(self.tau), _ptr(self.dv), _ptr(self.f),
+                                    _ptr(self.status), _ptr(self.obs), _ptr(self.frames), _ptr(self.ncon),
+                                    _ptr(self.con_pairs), _ptr(self.info), int(n_substeps), self._stream())
+        _lib.check(self._L, self._h, rc, "tsidb_step")
+        self.t += n_substeps * self.conf.dt
+        return self.tau, self.q, self.v, self.status, self.obs
+
+    def tick(self):
+        """TSID stage only (main.py:119-129)."""
+        with torch.cuda.device(self.device):
+            rc = self._L.tsidb_tick(self._h, _ptr(self.q), _ptr(self.v), _ptr(self.tau), _ptr(self.dv), _ptr(self.f),
+                                    _ptr(self.status), _ptr(self.obs), _ptr(self.frames), _ptr(self.info), self._stream())
+        _lib.check(self._L, self._h, rc, "tsidb_tick")
+        return self.tau, self.q, self.v, self.status, self.obs
+
+    def sim_step(self, teleport=True):
+        """Sim stage only (main.py:192-195); teleport=False steps the sim state on its own."""
+        with torch.cuda.device(self.device):
+            rc = self._L.tsidb_sim(self._h, _ptr(self.q) if teleport else None, _ptr(self.qpos), _ptr(self.qvel),
+                                   _ptr(self.qacc_warmstart), None, _ptr(self.ncon), _ptr(self.con_pairs),
+                                   _ptr(self.info), self._stream())
+        _lib.check(self._L, self._h, rc, "tsidb_sim")
+        return self.qpos, self.qvel
+
+    def rbd_terms(self, q=None, v=None):
+        """Rigid-body terms of computeProblemData (main.py:119) for inspection/tests."""
+        q = self.q if q is None else q
+        v = self.v if v is None else v
+        N = self.num_envs
+        z = lambda *s: torch.zeros(*s, dtype=self.dtype, device=self.device)
+        out = dict(M=z(N, NV, NV), h=z(N, NV), Jcom=z(N, 3, NV), Jf=z(N, 2, 6, NV), oMf=z(N, 2, 12), com=z(N, 3))
+        with torch.cuda.device(self.device):
+            rc = self._L.tsidb_rbd_terms(self._h, _ptr(q), _ptr(v), _ptr(out["M"]), _ptr(out["h"]), _ptr(out["Jcom"]),
+                                         _ptr(out["Jf"]), _ptr(out["oMf"]), _ptr(out["com"]), self._stream())
+        _lib.check(self._L, self._h, rc, "tsidb_rbd_terms")
+        return out
+
+    # ------------------------------------------------------------------ reference method surface
+    @staticmethod
+    def _frames_to_se3vec(fr):
+        """[.., 12] R row-major + p  ->  [.., 12] p + R column-major (tsid SE3ToVector)."""
+        R = fr[..., :9].reshape(*fr.shape[:-1], 3, 3)
+        return torch.cat([fr[..., 9:], R.transpose(-1, -2).reshape(*fr.shape[:-1], 9)], dim=-1)
+
+    def _mask(self, flag):
+        if isinstance(flag, torch.Tensor):
+            return flag.to(self.device).bool().reshape(-1)
+        return torch.full((self.num_envs,), bool(flag), dtype=torch.bool, device=self.device)
+
+    def _sample24(self, s):
+        if isinstance(s, torch.Tensor):
+            return s.to(self.device, self.dtype).reshape(self.num_envs, 24)
+        return torch.cat([s.pos, s.vel, s.acc], dim=-1).to(self.device, self.dtype).reshape(self.num_envs, 24)
+
+    def update_tasks(self, sampleLF, sampleRF, contact_LF, contact_RF):
+        """WalkController.py:189-209, batched: set both foot-task references, then switch contacts
+        on the edges of the (per-env) contact flags."""
+        self.foot_ref[:, 0] = self._sample24(sampleLF)
+        self.foot_ref[:, 1] = self._sample24(sampleRF)
+        cLF, cRF = self._mask(contact_LF), self._mask(contact_RF)
+        aLF, aRF = self.contactLF_active, self.contactRF_active
+        self.add_contact(left_foot=cLF & ~aLF, right_foot=cRF & ~aRF)
+        self.remove_contact(left_foot=~cLF & aLF, right_foot=~cRF & aRF)
+
+    def display(self, q):
+        """WalkController.py:211-213: viewer hook; no viewer exists here."""
+        return None
+
+    def remove_contact(self, left_foot=True, right_foot=True):
+        """WalkController.py:215-232 (as legacy/biped.py:168-189 makes it work): re-reference the foot
+        task at the current placement, drop the rigid contact."""
+        cur = self._frames_to_se3vec(self.frames)
+        for f, flag in ((0, left_foot), (1, right_foot)):
+            m = self._mask(flag) & self.contact_active[:, f].bool()
+            ref = torch.cat([cur[:, f], torch.zeros(self.num_envs, 12, dtype=self.dtype, device=self.device)], dim=-1)
+            self.foot_ref[:, f] = torch.where(m[:, None], ref, self.foot_ref[:, f])
+            self.contact_active[:, f] = torch.where(m, torch.zeros_like(self.contact_active[:, f]), self.contact_active[:, f])
+
+    def add_contact(self, left_foot=True, right_foot=True):
+        """WalkController.py:234-253: re-reference the contact at the current placement, add it back."""
+        cur = self._frames_to_se3vec(self.frames)
+        for f, flag in ((0, left_foot), (1, right_foot)):
+            m = self._mask(flag) & ~self.contact_active[:, f].bool()
+            self.contact_ref[:, f] = torch.where(m[:, None], cur[:, f], self.contact_ref[:, f])
+            self.contact_active[:, f] = torch.where(m, torch.ones_like(self.contact_active[:, f]), self.contact_active[:, f])
+
+    def get_cop(self, sol=None):
+        """WalkController.py:255-289: centre of pressure of the last tick's contact forces, [N,3];
+        rows are NaN where the reference would return None (not both feet in contact)."""
+        cop = self.obs[:, 56:59].clone()
+        both = self.contactLF_active & self.contactRF_active
+        cop[~both] = float("nan")
+        return cop
+
+    def integrate_dv(self, q, v, dv, dt):
+        """WalkController.py:291-295 for caller-held tensors: v updated in place, new q returned.
+        (step() integrates inside the kernel; this exists for callers that drive the pieces.)"""
+        v_mean = v + 0.5 * dt * dv
+        v += dt * dv
+        d = dt * v_mean
+        w = d[:, 3:6]
+        th = torch.linalg.norm(w, dim=-1, keepdim=True)
+        th2 = th * th
+        small = th < 1e-8
+        ths = torch.where(small, torch.ones_like(th), th)
+        b = torch.where(small, 0.5 - th2 / 24, (1 - torch.cos(ths)) / (ths * ths))
+        c = torch.where(small, 1.0 / 6 - th2 / 120, (ths - torch.sin(ths)) / (ths ** 3))
+        sh = torch.where(small, 0.5 - th2 / 48, torch.sin(0.5 * ths) / ths)
+        ch = torch.cos(0.5 * th)
+        wxv = torch.cross(w, d[:, :3], dim=-1)
+        pd = d[:, :3] + b * wxv + c * torch.cross(w, wxv, dim=-1)
+        x, y, z_, w_ = q[:, 3], q[:, 4], q[:, 5], q[:, 6]
+        R = torch.stack([1 - 2 * (y * y + z_ * z_), 2 * (x * y - w_ * z_), 2 * (x * z_ + w_ * y),
+                         2 * (x * y + w_ * z_), 1 - 2 * (x * x + z_ * z_), 2 * (y * z_ - w_ * x),
+                         2 * (x * z_ - w_ * y), 2 * (y * z_ + w_ * x), 1 - 2 * (x * x + y * y)], dim=-1).reshape(-1, 3, 3)
+        qn = q.clone()
+        qn[:, :3] = q[:, :3] + (R @ pd[:, :, None])[:, :, 0]
+        dq = torch.cat([sh * w, ch], dim=-1)
+        a = q[:, 3:7]
+        r = torch.stack([
+            a[:, 3] * dq[:, 0] + a[:, 0] * dq[:, 3] + a[:, 1] * dq[:, 2] - a[:, 2] * dq[:, 1],
+            a[:, 3] * dq[:, 1] - a[:, 0] * dq[:, 2] + a[:, 1] * dq[:, 3] + a[:, 2] * dq[:, 0],
+            a[:, 3] * dq[:, 2] + a[:, 0] * dq[:, 1] - a[:, 1] * dq[:, 0] + a[:, 2] * dq[:, 3],
+            a[:, 3] * dq[:, 3] - a[:, 0] * dq[:, 0] - a[:, 1] * dq[:, 1] - a[:, 2] * dq[:, 2]], dim=-1)
+        qn[:, 3:7] = r / torch.linalg.norm(r, dim=-1, keepdim=True)
+        qn[:, 7:] = q[:, 7:] + d[:, 6:]
+        return qn, v
+
+
+def map_tsid_to_mujoco(q_tsid, model: ModelBlob = None):
+    """main.py:11-44, batched: joint-angle targets in the sim's actuator order from a TSID q."""
+    model = model or ModelBlob()
+    idx = torch.as_tensor(np.asarray(model["mj_ctrl_qidx"]), dtype=torch.long, device=q_tsid.device)
+    return q_tsid[..., idx]
