@@ -1,0 +1,178 @@
+#!/usr/bin/env python3
+"""bench.py - env-steps/sec of the batched TSID + contact-dynamics hot path on N MI355X.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one batch: for every env one TSID tick (main.py:119-129)
+and one sim step (main.py:192-195), preceded by the walking reference update that config 3 needs
+(footstep schedule -> update_tasks) and, for N > 1, followed by the RCCL all-gather of the
+observations.  Workload = BASELINE.json configs[2] "4096 OP3 LIPM walking, 1 MI355X" per GPU (weak
+scaling: configs[3] = 8 x 4096 at N = 8).  Inputs are resident in HBM before the timed region.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+# SURVEY.md 8(d) accounting, split per kernel (words of the arithmetic type per env per launch):
+#   k_tick reads q 27, v 26, CoM ref 9, posture ref 20, foot refs 48, contact refs 24, flags 2 (156)
+#          writes q 27, v 26, tau 20, dv 26, f 24, status 1, obs 65 (189)
+#   k_sim  reads TSID q 27, qpos 27, qvel 26, qacc_warmstart 26 (106); writes qpos 27, qvel 26, qacc_warmstart 26 (79)
+TICK_WORDS = 156 + 189
+SIM_WORDS = 106 + 79
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured float4 copy)
+VALU_PEAK_TFLOPS = {"f64": 78.6, "f32": 157.3}
+NOMINAL_FLOP_PER_ENV_STEP = 0.5e6  # SURVEY.md 8(d), structure-exploiting estimate
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--envs-per-gpu", type=int, default=4096)
+    ap.add_argument("--dtype", choices=["f64", "f32"], default="f64")
+    ap.add_argument("--workload", choices=["walk", "stand"], default="walk")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline budget; 0 disables it")
+    ap.add_argument("--cpu-sample", type=int, default=256)
+    return ap.parse_args()
+
+
+def cpu_baseline(wc, seconds, sample):
+    """The oracle (a CPU port, float64) timed on this box's host cores, on a bounded sample of the
+    same workload: the first `sample` envs' state and references as they stand after warm-up."""
+    from oracle.oracle import Oracle, new_state
+    n = min(sample, wc.num_envs)
+    orc = Oracle(wc.model.raw)
+    st = new_state(n)
+    for k in ("q", "v", "qpos", "qvel", "com_ref", "posture_ref", "foot_ref", "contact_ref", "cop_frames", "contact_active"):
+        st[k][...] = getattr(wc, k)[:n].double().cpu().numpy().reshape(st[k].shape) if k != "contact_active" \
+            else wc.contact_active[:n].cpu().numpy()
+    st["qacc_ws"][...] = wc.qacc_warmstart[:n].double().cpu().numpy()
+    cores = len(os.sched_getaffinity(0))
+    orc.env_step_batch(wc.params, st, nthreads=cores)  # warm
+    t0 = time.perf_counter()
+    reps = 0
+    while time.perf_counter() - t0 < seconds:
+        orc.env_step_batch(wc.params, st, nthreads=cores)
+        reps += 1
+    el = time.perf_counter() - t0
+    # single-thread figure on a smaller slice
+    st1 = {k: np.ascontiguousarray(v[:32]) for k, v in st.items()}
+    t1 = time.perf_counter()
+    r1 = 0
+    while time.perf_counter() - t1 < min(3.0, seconds / 4):
+        orc.env_step_batch(wc.params, st1, nthreads=1)
+        r1 += 1
+    el1 = time.perf_counter() - t1
+    return dict(value=n * reps / el, unit="env-steps/s", cores=cores, kind="port",
+                sample=f"{n} envs (state + references captured after warm-up, references frozen) x {reps} env steps, "
+                       f"oracle/liboracle.so float64, OpenMP over envs",
+                value_1thread=32 * r1 / el1)
+
+
+def main():
+    args = parse()
+    from tsid_control_amd import RobotConfig, WalkController
+    from tsid_control_amd.sharding import ObsGather, init_distributed
+    from tsid_control_amd.walk_planner import WalkSchedule
+    import torch.distributed as dist
+
+    rank, local, world = init_distributed()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    dev = torch.device("cuda", local if world > 1 else 0)
+    torch.cuda.set_device(dev)
+    n = args.envs_per_gpu
+    conf = RobotConfig()
+    conf.dtype = args.dtype
+    wc = WalkController(conf, num_envs=n, device=dev)
+    torch.manual_seed(1 + rank)
+    sched = None
+    if args.workload == "walk":
+        lf, rf = wc.frames[0, 0, 9:11].cpu().numpy(), wc.frames[0, 1, 9:11].cpu().numpy()
+        sched = WalkSchedule.from_demo_paths(n, conf, dev, wc.dtype, seed=1 + rank, q0_feet=(lf, rf))
+    else:  # config 2: perturbed standing
+        wc.q[:, 7:] += (torch.rand(n, 20, dtype=wc.dtype, device=dev) - 0.5) * 0.1
+        wc.v[:] = torch.randn(n, 26, dtype=wc.dtype, device=dev) * 0.05
+    gather = ObsGather(n, 65, world, wc.dtype, dev)
+    total = args.warmup + args.steps
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+
+    def one_step(i, timed_idx=None):
+        if sched is not None:
+            t = i * conf.dt
+            sLF, sRF, cLF, cRF = sched.sample(t)
+            wc.update_tasks(sLF, sRF, cLF, cRF)
+            wc.com_ref[:, :2] = sched.com_xy(t)
+        if timed_idx is None:
+            wc.tick()
+            wc.sim_step()
+        else:
+            e = ev[timed_idx]
+            e[0].record(); wc.tick(); e[1].record(); wc.sim_step(); e[2].record()
+        gather(wc.obs)
+
+    for i in range(args.warmup):
+        one_step(i)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        one_step(args.warmup + k, k)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    el = time.perf_counter() - t0
+    elt = torch.tensor([el], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(elt, op=dist.ReduceOp.MAX)
+    el = float(elt.item())
+
+    tick_ms = sum(e[0].elapsed_time(e[1]) for e in ev) / args.steps
+    sim_ms = sum(e[1].elapsed_time(e[2]) for e in ev) / args.steps
+    wsz = 8 if args.dtype == "f64" else 4
+    dom, dom_ms, dom_words = ("k_tick", tick_ms, TICK_WORDS) if tick_ms >= sim_ms else ("k_sim", sim_ms, SIM_WORDS)
+    alg_bytes = n * dom_words * wsz
+    achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
+    n_bad = int((wc.status != 0).sum().item())
+
+    if rank == 0:
+        value = world * n * args.steps / el
+        out = {
+            "metric": "env-steps/sec (whole node)", "value": value, "unit": "env-steps/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": ("cfg3: 4096 OP3 LIPM walking per GPU (footstep schedule + swing trajectories -> "
+                                    "update_tasks each tick; TSID tick + sim step)" if args.workload == "walk" else
+                                    "cfg2: perturbed stand/balance per GPU"),
+                       "envs_per_gpu": n, "global_envs": n * world, "parallelism": f"env-sharded x{world}, obs all-gather",
+                       "qp_failed_envs_last_step": n_bad},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": dom_ms,
+                         "k_tick_ms": tick_ms, "k_sim_ms": sim_ms,
+                         "valu_frac_nominal": (n * NOMINAL_FLOP_PER_ENV_STEP / ((tick_ms + sim_ms) * 1e-3)) / (VALU_PEAK_TFLOPS[args.dtype] * 1e12)},
+        }
+        if world == 1 and args.cpu_seconds > 0:
+            out["cpu_baseline"] = cpu_baseline(wc, args.cpu_seconds, args.cpu_sample)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

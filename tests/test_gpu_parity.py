@@ -1,0 +1,250 @@
+"""GPU parity: the HIP path (through the C-ABI, via the WalkController facade) against the CPU oracle
+on the same seeded inputs.  Tolerances:
+  f64 path  - tau/dv/f-wrench 1e-7 abs, next q/v/qpos 1e-9, qvel 1e-6; status, contact pairs bit-exact
+  f32 path  - tau, dv, per-foot wrench rtol 1e-3 / atol 2e-3 on one tick from identical inputs
+The oracle itself is unpinned against tsid/pinocchio/mujoco (none available)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import oracle_state  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+NQ, NV = 27, 26
+
+
+def make(n, dtype="f64", **conf_over):
+    from tsid_control_amd import RobotConfig, WalkController
+    conf = RobotConfig()
+    conf.dtype = dtype
+    for k, v in conf_over.items():
+        setattr(conf, k, v)
+    return WalkController(conf, num_envs=n, device="cuda:0")
+
+
+def perturb(wc, seed=0, dq=0.05, dv=0.05):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    n = wc.num_envs
+    wc.q[:, 7:] += ((torch.rand(n, 20, generator=g, dtype=torch.float64) - 0.5) * 2 * dq).to(wc.device, wc.dtype)
+    wc.v[:] = (torch.randn(n, 26, generator=g, dtype=torch.float64) * dv).to(wc.device, wc.dtype)
+
+
+def mirror(wc):
+    """oracle state arrays holding exactly what the controller's tensors hold"""
+    from oracle.oracle import new_state
+    st = new_state(wc.num_envs)
+    for k in ("q", "v", "qpos", "qvel", "com_ref", "posture_ref", "foot_ref", "contact_ref", "cop_frames", "contact_active"):
+        st[k][...] = getattr(wc, k).cpu().numpy().reshape(st[k].shape)
+    st["qacc_ws"][...] = wc.qacc_warmstart.double().cpu().numpy()
+    return st
+
+
+def diff(t, a):
+    return float(np.abs(t.double().cpu().numpy().reshape(a.shape) - a).max())
+
+
+def wrench(f, params):
+    cp = params[19:31].reshape(4, 3)
+    T = np.zeros((6, 12))
+    for i in range(4):
+        T[:3, 3 * i:3 * i + 3] = np.eye(3)
+        T[3:, 3 * i:3 * i + 3] = np.array([[0, -cp[i, 2], cp[i, 1]], [cp[i, 2], 0, -cp[i, 0]], [-cp[i, 1], cp[i, 0], 0]])
+    f = np.asarray(f).reshape(-1, 2, 12)
+    return np.einsum("ij,nfj->nfi", T, f)
+
+
+def test_reset_matches_reference_init(oracle, standing):
+    wc = make(5)
+    assert diff(wc.q, np.tile(standing["q"], (5, 1))) < 1e-14
+    assert diff(wc.qpos, np.tile(standing["q"], (5, 1))) < 1e-14               # main.py:64
+    assert diff(wc.com_ref, np.tile(standing["com_ref"], (5, 1))) < 1e-14
+    assert diff(wc.contact_ref, np.tile(standing["contact_ref"], (5, 1, 1))) < 1e-14
+    assert diff(wc.foot_ref, np.tile(standing["foot_ref"], (5, 1, 1))) == 0
+    assert diff(wc.cop_frames, np.tile(standing["cop_frames"], (5, 1, 1))) < 1e-14
+    assert wc.contact_active.cpu().numpy().tolist() == [[1, 1]] * 5
+    assert abs(float(wc.q[0, 2]) - 0.331968) < 1e-6
+    # partial reset touches only the listed envs
+    wc.q += 1.0
+    wc.reset(env_ids=[1, 3])
+    assert diff(wc.q[[1, 3]], np.tile(standing["q"], (2, 1))) < 1e-14 and float((wc.q[[0, 2, 4]] - 1.0 - wc.q[[1, 3]][0]).abs().max()) < 1e-14
+
+
+def test_rbd_terms_f64(oracle):
+    wc = make(16)
+    perturb(wc, 1, dq=0.5, dv=1.0)
+    g = torch.Generator().manual_seed(2)
+    quat = torch.randn(16, 4, generator=g, dtype=torch.float64)
+    wc.q[:, 3:7] = (quat / quat.norm(dim=1, keepdim=True)).to(wc.device)
+    wc.q[:, :3] += torch.randn(16, 3, generator=g, dtype=torch.float64).to(wc.device)
+    t = wc.rbd_terms()
+    q, v = wc.q.cpu().numpy(), wc.v.cpu().numpy()
+    ref = [oracle.terms(q[e], v[e]) for e in range(16)]
+    for key in ("M", "h", "Jcom", "Jf", "oMf", "com"):
+        o = np.stack([r[key] for r in ref])
+        assert diff(t[key], o) < 1e-12 * max(1.0, np.abs(o).max()), key
+    M = t["M"].cpu().numpy()
+    assert np.abs(M - M.transpose(0, 2, 1)).max() == 0
+
+
+def test_rbd_terms_f32(oracle):
+    wc = make(16, "f32")
+    perturb(wc, 1, dq=0.5, dv=1.0)
+    wc.q[:, :3] += 3.0  # a few metres from the origin: base-centred spatial vectors keep fp32 accurate
+    t = wc.rbd_terms()
+    q, v = wc.q.double().cpu().numpy(), wc.v.double().cpu().numpy()
+    ref = [oracle.terms(q[e], v[e]) for e in range(16)]
+    for key, tol in (("M", 2e-6), ("h", 5e-5), ("Jcom", 1e-6), ("Jf", 2e-6), ("com", 2e-6)):
+        o = np.stack([r[key] for r in ref])
+        assert diff(t[key], o) < tol * max(1.0, np.abs(o).max()), key
+
+
+@pytest.mark.parametrize("sim", [True, False])
+def test_env_loop_f64_matches_oracle(oracle, sim):
+    """Config 2 in small: perturbed standing envs, 40 env steps, every per-env output every step."""
+    wc = make(48, sim_enabled=sim)
+    perturb(wc, 3)
+    st = mirror(wc)
+    for i in range(40):
+        wc.step()
+        oracle.env_step_batch(wc.params, st, nthreads=8)
+        assert np.array_equal(wc.status.cpu().numpy(), st["status"]), i
+        assert diff(wc.tau, st["tau"]) < 1e-7 and diff(wc.dv, st["dv"]) < 1e-7, i
+        assert np.abs(wrench(wc.f.cpu().numpy(), wc.params) - wrench(st["f"], wc.params)).max() < 1e-7, i
+        assert diff(wc.q, st["q"]) < 1e-9 and diff(wc.v, st["v"]) < 1e-9, i
+        assert diff(wc.obs, st["obs"]) < 1e-7, i
+        if sim:
+            assert np.array_equal(wc.ncon.cpu().numpy(), st["ncon"]), i
+            assert np.array_equal(wc.con_pairs.cpu().numpy(), st["con_geom"]), i      # integer contact indexing bit-exact
+            assert diff(wc.qpos, st["qpos"]) < 1e-9 and diff(wc.qvel, st["qvel"]) < 1e-6, i
+    assert int((wc.info[:, 1] > 18).sum()) > 0     # inequality constraints were active somewhere
+    if sim:
+        assert int(wc.ncon.max()) > 0               # contacts formed somewhere
+
+
+def test_single_tick_f32_within_tolerance(oracle):
+    wc = make(64, "f32")
+    perturb(wc, 4)
+    st = mirror(wc)
+    wc.tick()
+    for e in range(64):
+        out = oracle.tsid_tick(wc.params, st["q"][e], st["v"][e], st["com_ref"][e], st["posture_ref"][e], st["foot_ref"][e],
+                               st["contact_ref"][e], st["contact_active"][e], st["cop_frames"][e])
+        st["tau"][e], st["dv"][e], st["f"][e], st["status"][e] = out["tau"], out["dv"], out["f"], out["status"]
+    assert np.array_equal(wc.status.cpu().numpy(), st["status"])
+    tau, dv = wc.tau.double().cpu().numpy(), wc.dv.double().cpu().numpy()
+    assert np.allclose(tau, st["tau"], rtol=1e-3, atol=2e-3)
+    assert np.allclose(dv, st["dv"], rtol=1e-3, atol=2e-3)
+    assert np.allclose(wrench(wc.f.double().cpu().numpy(), wc.params), wrench(st["f"], wc.params), rtol=1e-3, atol=2e-3)
+    assert diff(wc.q, st["q"]) < 1e-5 and diff(wc.v, st["v"]) < 1e-4
+
+
+def test_sim_only_settles_on_the_floor_f64(oracle):
+    """Contact-solver stress without the teleport: drop 0.5 mm into the floor and let the sim settle."""
+    wc = make(4)
+    wc.qpos[:, 3:7] = torch.tensor([1.0, 0, 0, 0], dtype=wc.dtype, device=wc.device)
+    wc.qpos[:, 2] -= 0.0005
+    wc.qpos[1, 7] = 0.05
+    qpos, qvel, ws = (x.cpu().numpy().copy() for x in (wc.qpos, wc.qvel, wc.qacc_warmstart))
+    for i in range(300):
+        wc.sim_step(teleport=False)
+        for e in range(4):
+            oracle.sim_step(qpos[e], qvel[e], np.zeros(20), ws[e])
+    assert diff(wc.qpos, qpos) < 1e-8 and diff(wc.qvel, qvel) < 1e-5
+    assert float(wc.qvel.abs().max()) < 0.1 and 0.3315 < float(wc.qpos[0, 2]) < 0.3325
+    assert int(wc.ncon.min()) >= 2
+
+
+def test_contact_switching_and_walking_refs_f64(oracle):
+    """Config 3 in small: footstep schedule drives update_tasks (contact on/off edges, swing
+    references); the oracle receives the same reference arrays each tick."""
+    from tsid_control_amd.walk_planner import WalkSchedule
+    n = 12
+    wc = make(n, sim_enabled=False)
+    lf = wc.frames[0, 0, 9:11].cpu().numpy()
+    rf = wc.frames[0, 1, 9:11].cpu().numpy()
+    sched = WalkSchedule.from_demo_paths(n, wc.conf, wc.device, wc.dtype, seed=1, q0_feet=(lf, rf))
+    st = mirror(wc)
+    seen_single = False
+    for i in range(300):
+        t = i * wc.conf.dt
+        sLF, sRF, cLF, cRF = sched.sample(t)
+        wc.update_tasks(sLF, sRF, cLF, cRF)
+        for k in ("foot_ref", "contact_ref", "contact_active"):
+            st[k][...] = getattr(wc, k).cpu().numpy().reshape(st[k].shape)
+        seen_single |= bool((wc.contact_active.sum(dim=1) == 1).any())
+        wc.step()
+        oracle.env_step_batch(wc.params, st, nthreads=8)
+        assert np.array_equal(wc.status.cpu().numpy(), st["status"]), i
+        ok = st["status"] == 0
+        assert diff(wc.q[ok], st["q"][ok]) < 1e-8 and diff(wc.tau[ok], st["tau"][ok]) < 1e-6, i
+    assert seen_single
+
+
+def test_infeasible_envs_are_flagged_not_fatal(oracle):
+    wc = make(6)
+    wc.conf.fMin, wc.conf.fMax = 500.0, 400.0
+    wc.set_params()
+    q_before = wc.q.clone()
+    wc.step()
+    assert wc.status.cpu().numpy().tolist() == [1] * 6            # tsid HQP_STATUS_INFEASIBLE
+    assert torch.equal(wc.q, q_before)                            # a failed env does not integrate
+    wc.conf.fMin, wc.conf.fMax = 10.0, 1000.0
+    wc.set_params()
+    wc.step()
+    assert wc.status.cpu().numpy().tolist() == [0] * 6
+
+
+def test_shard_invariance_bitwise():
+    """1 vs 2 shards give bit-identical per-env results (what 1/2/4/8 GPUs must reproduce)."""
+    full = make(32)
+    perturb(full, 7)
+    a, b = make(16), make(16)
+    a.q.copy_(full.q[:16]); a.v.copy_(full.v[:16]); b.q.copy_(full.q[16:]); b.v.copy_(full.v[16:])
+    for _ in range(10):
+        full.step(); a.step(); b.step()
+    for name in ("q", "v", "qpos", "qvel", "tau", "obs"):
+        assert torch.equal(getattr(full, name), torch.cat([getattr(a, name), getattr(b, name)])), name
+
+
+def test_full_size_properties():
+    """BASELINE config sizes: 4096 envs (one GPU) - size-independent properties instead of the oracle."""
+    wc = make(4096)
+    for _ in range(5):
+        wc.step()
+    assert int(wc.status.abs().sum()) == 0
+    # identical envs stay bit-identical; standing: sum f_z = m g, zero acceleration, CoP between the feet
+    for name in ("q", "tau", "f", "qpos"):
+        t = getattr(wc, name)
+        assert torch.equal(t, t[0:1].expand_as(t)), name
+    fz = wc.f.reshape(4096, 8, 3)[:, :, 2].sum(dim=1)
+    assert float((fz - 2.893639 * 9.81).abs().max()) < 1e-3
+    assert float(wc.dv.abs().max()) < 1e-3
+    assert torch.isfinite(wc.obs).all()
+    perturb(wc, 11)
+    for _ in range(20):
+        wc.step()
+    assert int(wc.status.abs().sum()) == 0 and torch.isfinite(wc.q).all() and torch.isfinite(wc.qvel).all()
+    quat = wc.q[:, 3:7]
+    assert float((quat.norm(dim=1) - 1).abs().max()) < 1e-12
+
+
+def test_api_error_behaviour():
+    import ctypes as C
+    from tsid_control_amd import _lib
+    from tsid_control_amd.model import ModelBlob
+    from tsid_control_amd.params import P_COUNT
+    L = _lib.load()
+    h = C.c_void_p()
+    p = np.zeros(P_COUNT)
+    rc = L.tsidb_create(b"not a blob at all....", 21, p.ctypes.data_as(C.c_void_p), P_COUNT, 4, 0, 0, C.byref(h))
+    assert rc != 0 and b"TSIDBM01" in L.tsidb_last_error(h)
+    L.tsidb_destroy(h)
+    wc = make(2)
+    rc = L.tsidb_create(wc.model.raw, len(wc.model.raw), wc.params.ctypes.data_as(C.c_void_p), P_COUNT, 4, 99, 0, C.byref(h))
+    assert rc != 0 and b"device" in L.tsidb_last_error(h)
+    L.tsidb_destroy(h)
+    rc = L.tsidb_create(wc.model.raw, len(wc.model.raw), wc.params.ctypes.data_as(C.c_void_p), P_COUNT, 4, 0, 0, C.byref(h))
+    assert rc == 0
+    rc = L.tsidb_tick(h, None, None, None, None, None, None, None, None, None, None)
+    assert rc != 0 and b"tsidb_set_refs" in L.tsidb_last_error(h)   # references never registered
+    L.tsidb_destroy(h)

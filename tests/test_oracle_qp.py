@@ -1,0 +1,132 @@
+"""Oracle TSID assembly + dual active-set QP: structure (SURVEY.md section 3.1 dims), KKT optimality (the QP is
+strictly convex, so KKT <=> the unique optimum, independent of the solver that found it), physics at
+rest.  eiquadprog/tsid are not available to compare against (parity unpinned)."""
+import numpy as np
+
+NV = 26
+
+
+def kkt_check(qp, sol, tol=1e-7):
+    x, A, u = sol["x"], sol["A"], sol["u"]
+    neq = qp["CE"].shape[0]
+    assert np.abs(qp["CE"] @ x + qp["ce0"]).max() < 1e-9                      # primal feasibility (eq)
+    s = qp["CI"] @ x + qp["ci0"]
+    assert s.min() > -1e-5                                                     # primal feasibility (ineq)
+    act = A[neq:]
+    N = np.vstack([qp["CE"], qp["CI"][act]]) if len(act) else qp["CE"]
+    assert np.abs(qp["H"] @ x + qp["g"] - N.T @ u).max() < tol                 # stationarity
+    if len(act):
+        assert u[neq:].min() > -1e-9                                           # dual feasibility
+        assert np.abs(s[act]).max() < 1e-7                                     # complementarity
+    assert np.all(A[:neq] == -np.arange(1, neq + 1))
+
+
+def problem(oracle, params, standing, q, v, active=(1, 1), **over):
+    refs = {k: standing[k] for k in ("com_ref", "posture_ref", "foot_ref", "contact_ref")}
+    refs.update(over)
+    return oracle.assemble(params, q, v, refs["com_ref"], refs["posture_ref"], refs["foot_ref"], refs["contact_ref"],
+                           np.array(active, np.uint8))
+
+
+def test_dimensions_double_and_single_support(oracle, params, standing):
+    qp = problem(oracle, params, standing, standing["q"], standing["v"])
+    assert qp["H"].shape == (50, 50) and qp["CE"].shape == (18, 50) and qp["CI"].shape == (160, 50)
+    qp1 = problem(oracle, params, standing, standing["q"], standing["v"], active=(0, 1))
+    assert qp1["H"].shape == (38, 38) and qp1["CE"].shape == (12, 38) and qp1["CI"].shape == (126, 38)
+    assert qp1["slot_foot"] == [1, -1]
+    # H is block diagonal: dv block, one 12x12 block per contact
+    H = qp["H"]
+    assert np.abs(H[:26, 26:]).max() == 0 and np.abs(H[26:38, 38:]).max() == 0
+    assert np.abs(H - H.T).max() < 1e-15
+    assert np.allclose(H[26:38, 26:38], H[38:, 38:])
+
+
+def test_standing_solution_balances_gravity(oracle, params, standing):
+    qp = problem(oracle, params, standing, standing["q"], standing["v"])
+    sol = oracle.qp_solve(qp["_raw"])
+    assert sol["status"] == 0 and sol["iq"] == 18
+    kkt_check(qp, sol)
+    x = sol["x"]
+    assert np.abs(x[:26]).max() < 1e-4                                         # no acceleration at rest
+    fz = x[26:][2::3]
+    assert abs(fz.sum() - standing["terms"]["mass"] * 9.81) < 1e-3             # sum f_z = m g
+    assert fz.min() > 0
+    # independent solve of the equality-constrained problem (no inequality is active here)
+    K = np.block([[qp["H"], qp["CE"].T], [qp["CE"], np.zeros((18, 18))]])
+    xs = np.linalg.solve(K, np.concatenate([-qp["g"], -qp["ce0"]]))[:50]
+    assert np.abs(xs - x).max() < 1e-8
+
+
+def test_kkt_on_perturbed_states(oracle, params, standing):
+    rng = np.random.default_rng(4)
+    n_active = 0
+    for trial in range(40):
+        q = standing["q"].copy()
+        q[7:] += rng.uniform(-0.05, 0.05, 20)
+        v = rng.normal(0, 0.05 * (1 + trial % 4), NV)
+        qp = problem(oracle, params, standing, q, v)
+        sol = oracle.qp_solve(qp["_raw"])
+        assert sol["status"] == 0
+        kkt_check(qp, sol)
+        n_active += sol["iq"] - 18
+    assert n_active > 0                                                        # the active-set path was exercised
+
+
+def test_single_support_and_foot_reference(oracle, params, standing):
+    rng = np.random.default_rng(5)
+    q = standing["q"].copy()
+    q[7:] += rng.uniform(-0.02, 0.02, 20)
+    v = rng.normal(0, 0.02, NV)
+    # swing-foot reference 2 cm above its current placement
+    foot_ref = standing["foot_ref"].copy()
+    foot_ref[0, :12] = standing["contact_ref"][0]
+    foot_ref[0, 2] += 0.02
+    qp = problem(oracle, params, standing, q, v, active=(0, 1), foot_ref=foot_ref)
+    sol = oracle.qp_solve(qp["_raw"])
+    assert sol["status"] == 0
+    kkt_check(qp, sol)
+    t = oracle.terms(q, v)
+    a_lf = t["Jf"][0] @ sol["x"][:26] + t["af"][0]
+    assert a_lf[2] > 0                                                         # the free foot accelerates upward
+
+
+def test_infeasible_problem_is_reported(oracle, params, standing):
+    p = params.copy()
+    from tsid_control_amd.params import P_FMIN, P_FMAX
+    p[P_FMIN], p[P_FMAX] = 500.0, 400.0                                        # fMin > fMax: empty feasible set
+    qp = oracle.assemble(p, standing["q"], standing["v"], standing["com_ref"], standing["posture_ref"],
+                         standing["foot_ref"], standing["contact_ref"], np.array([1, 1], np.uint8))
+    sol = oracle.qp_solve(qp["_raw"])
+    assert sol["status"] == 1
+
+
+def test_max_iter_status(oracle, params, standing):
+    rng = np.random.default_rng(6)
+    q = standing["q"].copy(); q[7:] += rng.uniform(-0.05, 0.05, 20)
+    qp = problem(oracle, params, standing, q, rng.normal(0, 0.2, NV))
+    full = oracle.qp_solve(qp["_raw"])
+    assert full["status"] == 0 and full["iter"] > 2
+    assert oracle.qp_solve(qp["_raw"], max_iter=2)["status"] == 3
+
+
+def test_tick_outputs(oracle, params, standing):
+    q, v = standing["q"].copy(), np.zeros(NV)
+    out = oracle.tsid_tick(params, q, v, standing["com_ref"], standing["posture_ref"], standing["foot_ref"],
+                           standing["contact_ref"], np.array([1, 1], np.uint8), standing["cop_frames"])
+    assert out["status"] == 0
+    t = standing["terms"]
+    # tau = M_a dv + h_a - J_a^T f reproduces the unactuated rows too: base dynamics residual
+    T = np.zeros((6, 12))
+    cp = params[19:31].reshape(4, 3)
+    for i in range(4):
+        T[:3, 3 * i:3 * i + 3] = np.eye(3)
+        T[3:, 3 * i:3 * i + 3] = np.array([[0, -cp[i, 2], cp[i, 1]], [cp[i, 2], 0, -cp[i, 0]], [-cp[i, 1], cp[i, 0], 0]])
+    Jc = np.vstack([T.T @ t["Jf"][0], T.T @ t["Jf"][1]])
+    full = t["M"] @ out["dv"] + t["h"] - Jc.T @ out["f"]
+    assert np.abs(full[:6]).max() < 1e-9 and np.abs(full[6:] - out["tau"]).max() < 1e-12
+    assert np.abs(out["tau"]).max() < 50.0
+    # obs = q v com cop LF RF ; cop lies between the feet
+    obs = out["obs"]
+    assert np.allclose(obs[:27], q) and np.allclose(obs[27:53], v)
+    assert np.allclose(obs[53:56], t["com"]) and np.allclose(obs[59:62], t["oMf"][0][9:])
+    assert t["oMf"][1][9] < obs[56] < t["oMf"][0][9]

@@ -533,7 +533,9 @@ __device__ int qp_solve(const DevModel<T> &m, TickLds<T> &L, QpCtx<T> &c, int la
       psi += sv < 0 ? sv : T(0);
     }
     psi = wave_sum(psi);
-    if (fabs(psi) <= T(c.nin) * Eps<T>::v * c1 * c2 * T(100)) { status = 0; break; }
+    // eiquadprog's feasibility tolerance is stated in float64 epsilons; it is a tolerance on the
+    // constraint values, not a rounding bound, so it does not widen with the arithmetic type
+    if (fabs(psi) <= T(c.nin) * T(2.220446049250313e-16) * c1 * c2 * T(100)) { status = 0; break; }
     if (lane < n) L.xold[lane] = L.x[lane];
     if (lane < c.iq) { L.uold[lane] = L.u[lane]; L.Aold[lane] = L.A[lane]; }
     const int iq_old = c.iq;
