@@ -49,6 +49,20 @@ def parse():
     return ap.parse_args()
 
 
+def host_cores():
+    """Host cores this process may actually use: affinity mask capped by the cgroup CPU quota (the GPU
+    box hands each 1-GPU job a 16-CPU share of a 256-thread host)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = Path("/sys/fs/cgroup/cpu.max").read_text().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    cap = int(os.environ.get("TSIDB_CPU_THREADS", "16"))
+    return max(1, min(n, cap))
+
+
 def cpu_baseline(wc, seconds, sample):
     """The oracle (a CPU port, float64) timed on this box's host cores, on a bounded sample of the
     same workload: the first `sample` envs' state and references as they stand after warm-up."""
@@ -60,7 +74,7 @@ def cpu_baseline(wc, seconds, sample):
         st[k][...] = getattr(wc, k)[:n].double().cpu().numpy().reshape(st[k].shape) if k != "contact_active" \
             else wc.contact_active[:n].cpu().numpy()
     st["qacc_ws"][...] = wc.qacc_warmstart[:n].double().cpu().numpy()
-    cores = len(os.sched_getaffinity(0))
+    cores = host_cores()
     orc.env_step_batch(wc.params, st, nthreads=cores)  # warm
     t0 = time.perf_counter()
     reps = 0
