@@ -1,0 +1,43 @@
+"""Phase breakdown of k_tick / k_sim from in-kernel shader-clock stamps (diagnostic build only).
+
+    hipcc ... -DTSIDB_STAMPS -o gpurun_out/libtsidb_stamps.so tsidb_api.hip
+    TSIDB_LIB_PATH=gpurun_out/libtsidb_stamps.so python tools/stamp_profile.py f64 4096
+Reads SHARES, not run time (stamps fence the schedule)."""
+import ctypes as C, sys
+import numpy as np, torch
+sys.path.insert(0, ".")
+from tsid_control_amd import RobotConfig, WalkController, _lib
+
+dtype = sys.argv[1] if len(sys.argv) > 1 else "f64"
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
+conf = RobotConfig(); conf.dtype = dtype
+wc = WalkController(conf, num_envs=N)
+torch.manual_seed(0)
+wc.q[:, 7:] += (torch.rand(N, 20, dtype=wc.dtype, device=wc.device) - 0.5) * 0.1
+wc.v[:] = torch.randn(N, 26, dtype=wc.dtype, device=wc.device) * 0.05
+for _ in range(5): wc.step()
+torch.cuda.synchronize()
+L = _lib.load()
+n = min(N, 8192)
+buf = np.zeros((n, 32), dtype=np.uint64)
+L.tsidb_debug_stamps.argtypes = [C.c_void_p, C.c_int]
+rc = L.tsidb_debug_stamps(buf.ctypes.data_as(C.c_void_p), n)
+assert rc == 0
+b = buf.astype(np.int64)
+names_t = ["rbd_terms", "rhs+Dyn", "H assemble", "cholesky", "fwdsub+inv+J write", "equalities(18)", "(unused)", "inequality loop", "decode+integrate"]
+idx_t = [(0, 1), (1, 2), (2, 3), (3, 4), (4, 5), (5, 6), None, (6, 8), (8, 9)]
+print(f"k_tick {dtype} N={N}: qp iters mean {wc.info[:,0].float().mean():.2f} max {int(wc.info[:,0].max())}; iq mean {wc.info[:,1].float().mean():.1f}")
+tot = np.median(b[:, 9] - b[:, 0])
+for nm, ix in zip(names_t, idx_t):
+    if ix is None: continue
+    d = np.median(b[:, ix[1]] - b[:, ix[0]])
+    print(f"  {nm:24s} {d:10.0f} cyc  {100*d/tot:5.1f}%")
+print(f"  {'total':24s} {tot:10.0f} cyc")
+names_s = ["kin+bias+M", "qacc_smooth chol", "collision", "rows+warmstart", "newton loop", "euler+write"]
+idx_s = [(16, 17), (17, 18), (18, 19), (19, 20), (20, 21), (21, 22)]
+tot = np.median(b[:, 22] - b[:, 16])
+print(f"k_sim: ncon mean {wc.ncon.float().mean():.1f}; newton iters mean {wc.info[:,2].float().mean():.2f}")
+for nm, ix in zip(names_s, idx_s):
+    d = np.median(b[:, ix[1]] - b[:, ix[0]])
+    print(f"  {nm:24s} {d:10.0f} cyc  {100*d/tot:5.1f}%")
+print(f"  {'total':24s} {tot:10.0f} cyc")

@@ -4,7 +4,10 @@ import ctypes as C
 from pathlib import Path
 
 _HERE = Path(__file__).parent
-LIB_PATH = _HERE / "libtsidb.so"
+import os
+
+# TSIDB_LIB_PATH selects a diagnostic build (tools/stamp_profile.py); the product default is in-tree
+LIB_PATH = Path(os.environ.get("TSIDB_LIB_PATH", _HERE / "libtsidb.so"))
 
 SYMBOLS = ["tsidb_create", "tsidb_destroy", "tsidb_last_error", "tsidb_set_params", "tsidb_set_refs", "tsidb_reset",
            "tsidb_tick", "tsidb_sim", "tsidb_step", "tsidb_rbd_terms", "tsidb_lds_bytes"]

@@ -509,6 +509,12 @@ int tsidb_rbd_terms(tsidb_handle h, const void *q, const void *v, void *M, void 
   GUARD_END
 }
 
+#ifdef TSIDB_STAMPS
+int tsidb_debug_stamps(unsigned long long *out, int n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamp), sizeof(unsigned long long) * 32 * (size_t)n);
+}
+#endif
+
 int tsidb_lds_bytes(int dtype, int which) {
   if (dtype == TSIDB_F64) return which == 0 ? (int)sizeof(TickLds<double>) : (int)sizeof(SimLds<double>);
   return which == 0 ? (int)sizeof(TickLds<float>) : (int)sizeof(SimLds<float>);

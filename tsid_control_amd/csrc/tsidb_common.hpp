@@ -4,6 +4,14 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#ifdef TSIDB_STAMPS
+// diagnostic build only (tools/stamp_profile.py): shader-clock stamps per phase, never in the product .so
+__device__ unsigned long long g_stamp[8192][32];
+#define TSIDB_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 8192) g_stamp[blockIdx.x][k] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define TSIDB_STAMP(k) do { } while (0)
+#endif
+
 namespace tsidb {
 
 constexpr int NJ = 21;   // TSID joints incl. the free-flyer root (pinocchio order)

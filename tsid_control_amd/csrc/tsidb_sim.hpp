@@ -144,6 +144,7 @@ __device__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L, int lane, const
   const T MINVAL = T(1e-15);
   const bool quirks = m.params[P_QUIRKS] != 0;
 
+  TSIDB_STAMP(16);
   // ---- stage state; teleport the base and map joint targets (main.py:192-194)
   if (lane < NQ) {
     T val = qpos_g[lane];
@@ -298,6 +299,7 @@ __device__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L, int lane, const
   } else if (lane >= 32 && lane < 38) L.xv[lane - 32] = 0;
   __syncthreads();
   if (lane < NV) { qfs += L.xv[lane]; L.qfs[lane] = qfs; }
+  TSIDB_STAMP(17);
   // ---- qacc_smooth = M^-1 qfrc_smooth
   T arow[NV];
 #pragma unroll
@@ -307,6 +309,7 @@ __device__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L, int lane, const
   int fail = spd ? 0 : 1;
   if (lane < NV) L.qas[lane] = qas;
 
+  TSIDB_STAMP(18);
   // ---- collision: floor plane (z = 0, normal +z) against each body's convex hull
   const T margin = 0, tie_tol = m.opt[6];
   int ncon = 0;
@@ -361,6 +364,7 @@ __device__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L, int lane, const
   if (lane == 0 && ncon_out) ncon_out[0] = ncon;
   if (con_out && lane < MAXCON) con_out[lane] = lane < ncon ? ((L.cbody[lane] << 16) | L.cvert[lane]) : -1;
 
+  TSIDB_STAMP(19);
   // ---- constraint rows: frictionloss (lane = dof), pyramidal contact rows (lane = contact)
   const T mu = m.contact[0];
   const T timeconst = m.contact[1] > 2 * dt ? m.contact[1] : 2 * dt, dampratio = m.contact[2];
@@ -436,6 +440,7 @@ __device__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L, int lane, const
     Ma = mulM(L, L.xv, lane);
     jar_of(qacc);
 
+    TSIDB_STAMP(20);
     const T scale = T(1) / (m.meaninertia * NV);
     T cost = 0;
     int iter = 0;
@@ -609,6 +614,7 @@ __device__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L, int lane, const
     solver_iter = iter;
   }
   __syncthreads();
+  TSIDB_STAMP(21);
   // ---- semi-implicit Euler, write back
   if (lane < NV) {
     const T vn = L.qvel[lane] + dt * qacc;
@@ -641,6 +647,7 @@ __device__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L, int lane, const
   __syncthreads();
   if (lane < NQ) qpos_g[lane] = L.qpos[lane];
   if (lane == 0 && info) { info[2] = solver_iter; info[3] = fail; }
+  TSIDB_STAMP(22);
 }
 
 } // namespace tsidb

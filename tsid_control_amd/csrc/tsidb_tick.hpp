@@ -59,6 +59,9 @@ __device__ __forceinline__ double rdlane(double v, int src) {
   return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
 }
 
+__device__ __forceinline__ float rsqrt_t(float x) { return 1.0f / sqrtf(x); }
+__device__ __forceinline__ double rsqrt_t(double x) { return 1.0 / sqrt(x); }
+
 // --------------------------------------------------------------------------- rigid-body terms
 // Inputs L.qs, L.vs.  Outputs: L.Dyn (M part, rest zero), L.h, L.Jf, L.Jcom, L.oMf, L.vf, L.af,
 // L.com, L.vcom, L.acomd.  Spatial vectors are [lin; ang] in world axes about the base origin O.
@@ -487,36 +490,8 @@ __device__ void delete_constraint(TickLds<T> &L, QpCtx<T> &c, int lane, int l) {
 template <typename T>
 __device__ int qp_solve(const DevModel<T> &m, TickLds<T> &L, QpCtx<T> &c, int lane, T c1, T c2, int max_iter, int &iter_out) {
   const int n = c.n;
-  c.iq = 0;
-  c.R_norm = 1;
   const T INF = Eps<T>::inf;
-  // ---------------- equality constraints
-  for (int i = 0; i < c.p; i++) {
-    T ce0;
-    int i0 = 0, i1 = n;
-    T val = 0;
-    if (i < 6) {
-      if (lane < n) val = L.Dyn[i * LDD + lane];
-      ce0 = L.h[i];
-    } else {
-      const int s = (i - 6) / 6, rr = (i - 6) % 6, f = c.slot_foot[s];
-      if (lane < NV) val = L.Jf[(6 * f + rr) * LDF + lane];
-      ce0 = -L.arhs[f][rr];
-      i1 = NV;
-    }
-    if (lane < n) L.np[lane] = val;
-    __syncthreads();
-    T zz, znp;
-    step_direction(L, c, lane, i0, i1, zz, znp);
-    T npx = wave_sum(lane < n ? val * L.x[lane] : T(0));
-    T t2 = 0;
-    if (fabs(zz) > Eps<T>::v) t2 = (-npx - ce0) / znp;
-    if (lane < n) L.x[lane] += t2 * L.z[lane];
-    if (lane < c.iq) L.u[lane] -= t2 * L.r[lane];
-    if (lane == 0) { L.u[c.iq] = t2; L.A[i] = -i - 1; }
-    __syncthreads();
-    if (!add_constraint(L, c, lane)) { iter_out = 0; return 4; }
-  }
+  // the equality constraints are already in the working set (c.iq == c.p, J, R, x, u, A in LDS)
   for (int r = lane; r < c.nin; r += WAVE) L.cstate[r] = 0;
   __syncthreads();
 
@@ -627,11 +602,13 @@ __device__ void tsid_tick_env(const DevModel<T> &m, TickLds<T> &L, int lane, T *
                               const T *posture_ref, const T *foot_ref, const T *contact_ref,
                               const uint8_t *cact, const T *cop_frames, T *tau, T *dv, T *fout, int *status_out,
                               T *obs, int *info) {
+  TSIDB_STAMP(0);
   // ---- stage state
   if (lane < NQ) L.qs[lane] = q[lane];
   if (lane < NV) L.vs[lane] = v[lane];
   __syncthreads();
   rbd_terms(m, L, lane);
+  TSIDB_STAMP(1);
 
   QpCtx<T> c;
   c.nslot = 0;
@@ -664,6 +641,7 @@ __device__ void tsid_tick_env(const DevModel<T> &m, TickLds<T> &L, int lane, T *
     L.Dyn[r * LDD + NV + cc] = -a;
   }
   __syncthreads(); // kinematics scratch is dead from here on
+  TSIDB_STAMP(2);
 
   // ---- Hessian block of dv in registers: lane i owns row i
   const T w_foot = m.params[P_W_FOOT], w_com = m.params[P_W_COM], w_post = m.params[P_W_POSTURE], reg = m.params[P_HESS_REG];
@@ -699,60 +677,213 @@ __device__ void tsid_tick_env(const DevModel<T> &m, TickLds<T> &L, int lane, T *
   for (int j = 0; j < NV; j++) c1 += rdlane(a[j], j);
   c1 += T(c.nslot) * m.Hf_trace;
 
-  // ---- Cholesky in registers (right-looking; lane i holds row i of L in a[0..i])
+  int qp_status = -1, qp_iters = 0;
+  TSIDB_STAMP(3);
+  // ---- Cholesky in registers (right-looking; lane i holds row i of L in a[0..i]); rd[k] = 1/L[k][k]
   bool spd = true;
+  T rd[NV];
 #pragma unroll
   for (int k = 0; k < NV; k++) {
     const T akk = rdlane(a[k], k);
     if (!(akk > 0)) spd = false;
-    const T lkk = sqrt(akk > 0 ? akk : T(1));
-    const T lik = lane == k ? lkk : a[k] / lkk;
+    const T rk = rsqrt_t(akk > 0 ? akk : T(1));
+    rd[k] = rk;
+    const T lik = lane == k ? akk * rk : a[k] * rk;
     a[k] = lik;
 #pragma unroll
     for (int j = k + 1; j < NV; j++) a[j] -= lik * rdlane(lik, j);
   }
-  // ---- y = L^-1 (-g) by forward substitution, X = L^-1 column per lane (= row of L^-T)
-  T acc = -gi, yv = 0;
+  TSIDB_STAMP(4);
+  // ---- three forward substitutions with L share its broadcast entries:
+  //   y  = L^-1 (-g)                      (uniform, lane i contributes y_i)
+  //   xr = L^-1 e_lane                    (column `lane` of L^-1 = row `lane` of J0 = L^-T)
+  //   bc = L^-1 CE[lane][0:26]^T          (column `lane` of B = J0^T CE^T, lanes < p)
+  const int p = c.p;
+  T bc[NVAR], jr[NVAR];
+  {
+    T acc = -gi;
+    T yv = 0;
+    // CE row `lane`: base dynamics rows come from Dyn, contact motion rows from the frame Jacobians
+    const bool isbase = lane < 6;
+    const int crow = lane < 6 ? lane : (lane < p ? 6 * c.slot_foot[(lane - 6) / 6] + (lane - 6) % 6 : 0);
 #pragma unroll
-  for (int k = 0; k < NV; k++) {
-    const T yk = rdlane(acc, k) / rdlane(a[k], k);
-    if (lane == k) yv = yk;
-    acc -= a[k] * yk;
+    for (int i = 0; i < NV; i++) {
+      T xs = lane == i ? T(1) : T(0);
+      T bs = lane < p ? (isbase ? L.Dyn[crow * LDD + i] : L.Jf[crow * LDF + i]) : T(0);
+#pragma unroll
+      for (int k = 0; k < i; k++) {
+        const T lik = rdlane(a[k], i);
+        xs -= lik * jr[k];
+        bs -= lik * bc[k];
+      }
+      jr[i] = xs * rd[i];
+      bc[i] = bs * rd[i];
+      const T yi = rdlane(acc, i) * rd[i];
+      if (lane == i) yv = yi;
+      acc -= a[i] * yi;
+    }
+    // x0 = L^-T y ; c_k = ce0_k + B[:,k] . y ; trace(J0)
+    T x0 = 0, c2 = 0, ck = 0;
+#pragma unroll
+    for (int i = 0; i < NV; i++) {
+      const T yi = rdlane(yv, i);
+      x0 += jr[i] * yi;
+      ck += bc[i] * yi;
+      c2 += rdlane(jr[i], i);
+    }
+    c2 += T(c.nslot) * m.Jf0_trace;
+    if (lane < 6) ck += L.h[lane];
+    else if (lane < p) ck -= L.arhs[c.slot_foot[(lane - 6) / 6]][(lane - 6) % 6];
+    // force rows: J0 row of the constant block; B rows 26.. = L_f^-1 (-Jc)^T for the base-dynamics columns
+#pragma unroll
+    for (int j = NV; j < NVAR; j++) { jr[j] = 0; bc[j] = 0; }
+    if (lane >= NV && lane < n) {
+#pragma unroll
+      for (int i = 0; i < NV; i++) jr[i] = 0;
+      const int e = (lane - NV) % 12, sl = (lane - NV) / 12;
+#pragma unroll
+      for (int s2 = 0; s2 < 2; s2++)
+#pragma unroll
+        for (int b = 0; b < 12; b++)
+          if (s2 == sl && b >= e) jr[NV + 12 * s2 + b] = m.Jf0[e][b];
+    }
+    if (lane >= n) {
+#pragma unroll
+      for (int i = 0; i < NV; i++) jr[i] = 0;
+    }
+    if (lane < 6) {
+      for (int s2 = 0; s2 < c.nslot; s2++) {
+        T ce[12];
+#pragma unroll
+        for (int b = 0; b < 12; b++) ce[b] = L.Dyn[lane * LDD + NV + 12 * s2 + b];
+#pragma unroll
+        for (int e = 0; e < 12; e++) {
+          T sacc = 0;
+#pragma unroll
+          for (int b = 0; b <= e; b++) sacc += m.Jf0[b][e] * ce[b];
+#pragma unroll
+          for (int s3 = 0; s3 < 2; s3++)
+            if (s3 == s2) bc[NV + 12 * s3 + e] = sacc;
+        }
+      }
+    }
+    TSIDB_STAMP(5);
+    // ---- Householder QR of B (columns in lanes 0..p-1) applied to J (rows in lanes 0..n-1)
+    T R_norm = 1;
+    bool degenerate = false;
+#pragma unroll
+    for (int k = 0; k < 18; k++) {
+      if (k < p) {
+        // lane k owns column k: alpha, tail norm, reflector scale
+        T sig = 0;
+#pragma unroll
+        for (int i = k + 1; i < NVAR; i++) sig += bc[i] * bc[i];
+        const T alpha = rdlane(bc[k], k), sigma = rdlane(sig, k);
+        T dkk = alpha;
+        if (sigma > 0) {
+          const T nrm = sqrt(alpha * alpha + sigma);
+          const T v0 = alpha + (alpha >= 0 ? nrm : -nrm);
+          const T beta = T(2) / (v0 * v0 + sigma);
+          dkk = alpha >= 0 ? -nrm : nrm;
+          // s = v . b_col (lanes > k), w = J_row . v (all lanes)
+          T sb = v0 * bc[k], wj = v0 * jr[k];
+#pragma unroll
+          for (int i = k + 1; i < NVAR; i++) {
+            const T vi = rdlane(bc[i], k);
+            sb += vi * bc[i];
+            wj += vi * jr[i];
+          }
+          sb *= beta; wj *= beta;
+          const bool upd = lane > k; // columns <= k are final (their rows >= k are already zero)
+          jr[k] -= wj * v0;
+          if (upd) bc[k] -= sb * v0;
+#pragma unroll
+          for (int i = k + 1; i < NVAR; i++) {
+            const T vi = rdlane(bc[i], k); // lane k's column is untouched until the loop ends
+            jr[i] -= wj * vi;
+            if (upd) bc[i] -= sb * vi;
+          }
+          if (lane == k) {
+            bc[k] = dkk;
+#pragma unroll
+            for (int i = k + 1; i < NVAR; i++) bc[i] = 0;
+          }
+        }
+        const T ad = fabs(dkk);
+        if (ad <= Eps<T>::v * R_norm) degenerate = true;
+        if (ad > R_norm) R_norm = ad;
+      }
+    }
+    // ---- R^T t = -c (forward), u = R^-1 t (backward, uniform), x = x0 + J[:, :p] t
+    T tacc = -ck, tv[18], uv[18];
+#pragma unroll
+    for (int i = 0; i < 18; i++) {
+      tv[i] = 0;
+      if (i < p) {
+        tv[i] = rdlane(tacc, i) / rdlane(bc[i], i);
+        tacc -= bc[i] * tv[i];
+      }
+    }
+#pragma unroll
+    for (int j = 17; j >= 0; j--) {
+      uv[j] = 0;
+      if (j < p) {
+        T ua = tv[j];
+#pragma unroll
+        for (int mm = j + 1; mm < 18; mm++)
+          if (mm < p) ua -= rdlane(bc[j], mm) * uv[mm];
+        uv[j] = ua / rdlane(bc[j], j);
+      }
+    }
+    T xeq = lane < NV ? x0 : T(0);
+#pragma unroll
+    for (int k = 0; k < 18; k++) xeq += jr[k] * tv[k];
+    TSIDB_STAMP(6);
+    // ---- first feasibility sweep straight from registers' result; J / R go to LDS only if the
+    //      active-set iterations are actually needed
+    if (lane < n) { L.x[lane] = xeq; L.g[lane] = gi; }
+    __syncthreads();
+    c.iq = p;
+    c.R_norm = R_norm;
+    int iters = 1;
+    int status = -1;
+    if (!spd) status = 2;
+    else if (degenerate) { status = 4; iters = 0; }
+    else {
+      T psi = 0;
+      for (int r = lane; r < c.nin; r += WAVE) {
+        const T sv = row_value(m, L, c, r);
+        psi += sv < 0 ? sv : T(0);
+      }
+      psi = wave_sum(psi);
+      if (fabs(psi) <= T(c.nin) * T(2.220446049250313e-16) * c1 * c2 * T(100)) status = 0;
+    }
+    if (status < 0) {
+#pragma unroll
+      for (int j = 0; j < NVAR; j++)
+        if (lane < n) L.J[lane * LDJ + j] = jr[j];
+      if (lane < p) {
+#pragma unroll
+        for (int i = 0; i < 18; i++)
+          if (i <= lane) L.R[rcol(lane) + i] = bc[i];
+      }
+      if (lane < NVAR + 2) {
+        T uu = 0;
+#pragma unroll
+        for (int k = 0; k < 18; k++)
+          if (lane == k) uu = uv[k];
+        L.u[lane] = uu;
+        L.A[lane] = lane < p ? -lane - 1 : 0;
+      }
+      __syncthreads();
+      status = qp_solve(m, L, c, lane, c1, c2, (int)m.params[P_MAX_ITER], iters);
+    }
+    qp_status = status;
+    qp_iters = iters;
   }
-  T xr[NV]; // xr[i] = X[i][lane] = (L^-1)[i][lane] = (L^-T)[lane][i]
-#pragma unroll
-  for (int i = 0; i < NV; i++) {
-    T sacc = lane == i ? T(1) : T(0);
-#pragma unroll
-    for (int k = 0; k < i; k++) sacc -= rdlane(a[k], i) * xr[k];
-    xr[i] = sacc / rdlane(a[i], i);
-  }
-  // x0 = L^-T y : row `lane` of L^-T dotted with y
-  T x0 = 0, c2 = 0;
-#pragma unroll
-  for (int i = 0; i < NV; i++) {
-    x0 += xr[i] * rdlane(yv, i);
-    c2 += rdlane(xr[i], i);
-  }
-  c2 += T(c.nslot) * m.Jf0_trace;
-  // ---- write J = L^-T (block diagonal) and x0, g to LDS
-  for (int i = lane; i < NVAR * LDJ; i += WAVE) L.J[i] = 0;
-  __syncthreads();
-  if (lane < NV) {
-#pragma unroll
-    for (int i = 0; i < NV; i++)
-      if (i >= lane) L.J[lane * LDJ + i] = xr[i];
-  } else if (lane < n) {
-    const int e = (lane - NV) % 12, off = NV + 12 * ((lane - NV) / 12);
-    for (int b = e; b < 12; b++) L.J[lane * LDJ + off + b] = m.Jf0[e][b];
-  }
-  if (lane < n) { L.x[lane] = lane < NV ? x0 : T(0); L.g[lane] = gi; }
-  if (lane < NVAR + 2) { L.u[lane] = 0; L.A[lane] = 0; }
-  __syncthreads();
+  int status = qp_status, iters = qp_iters;
 
-  int iters = 0;
-  int status = spd ? qp_solve(m, L, c, lane, c1, c2, (int)m.params[P_MAX_ITER], iters) : 2;
-
+  TSIDB_STAMP(8);
   // ---- decode: dv, f, tau = M_a dv + h_a - J_a^T f
   if (lane < NV) dv[lane] = L.x[lane];
   if (lane < 24) {
@@ -851,6 +982,7 @@ __device__ void tsid_tick_env(const DevModel<T> &m, TickLds<T> &L, int lane, T *
     if (lane < NQ) obs[lane] = L.qs[lane];
     if (lane < NV) obs[NQ + lane] = L.vs[lane];
   }
+  TSIDB_STAMP(9);
 }
 
 } // namespace tsidb
