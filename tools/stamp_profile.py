@@ -41,3 +41,5 @@ for nm, ix in zip(names_s, idx_s):
     d = np.median(b[:, ix[1]] - b[:, ix[0]])
     print(f"  {nm:24s} {d:10.0f} cyc  {100*d/tot:5.1f}%")
 print(f"  {'total':24s} {tot:10.0f} cyc")
+for nm, k in (("  newton: eval+grad", 24), ("  newton: Hessian build", 25), ("  newton: chol+solve", 26), ("  newton: line search+move", 27)):
+    print(f"{nm:26s} {np.median(b[:, k]):10.0f} cyc (sum over iterations)")

@@ -176,7 +176,7 @@ struct tsidb_ctx {
   int device = 0, dtype = 0, num_envs = 0;
   Blob blob;
   std::vector<double> params;
-  void *d_model = nullptr, *d_hull = nullptr;
+  void *d_model = nullptr, *d_hull = nullptr, *d_box = nullptr;
   int *d_eadr = nullptr, *d_edge = nullptr;
   const void *com_ref = nullptr, *posture_ref = nullptr, *foot_ref = nullptr, *contact_ref = nullptr, *cop_frames = nullptr;
   const uint8_t *contact_active = nullptr;
@@ -310,7 +310,12 @@ static void build_model(tsidb_ctx *h, DevModel<T> &m) {
   m.opt[0] = (T)P[P_DT];                         // main.py:52 mj_model.opt.timestep = conf.dt
   m.opt[6] = sizeof(T) == 8 ? (T)1e-9 : (T)2e-6; // support-vertex tie tolerance
   for (int i = 0; i < 8; i++) m.contact[i] = (T)ct[i];
-  m.hull_vert = (const T *)h->d_hull;
+  const uint32_t nvert = h->blob.count("mj_hull_vert") / 3;
+  m.hull_x = (const T *)h->d_hull;
+  m.hull_y = m.hull_x + nvert;
+  m.hull_z = m.hull_y + nvert;
+  memcpy(m.chunk_adr, b.i32("mj_chunk_adr", NB + 1), sizeof m.chunk_adr);
+  m.chunk_box = (const T *)h->d_box;
   m.hull_eadr = h->d_eadr;
   m.hull_edge = h->d_edge;
 }
@@ -322,13 +327,21 @@ static void upload_model(tsidb_ctx *h) {
     const uint32_t nvert3 = b.count("mj_hull_vert"), nedge = b.count("mj_hull_edge"), neadr = b.count("mj_hull_eadr");
     const double *hv = b.f64("mj_hull_vert", 0);
     std::vector<T> hvt(nvert3);
-    for (uint32_t i = 0; i < nvert3; i++) hvt[i] = (T)hv[i];
+    for (uint32_t i = 0; i < nvert3; i++) hvt[(i % 3) * (nvert3 / 3) + i / 3] = (T)hv[i]; // AoS -> SoA
     HIP_OK(hipMalloc(&h->d_hull, nvert3 * sizeof(T)));
     HIP_OK(hipMemcpy(h->d_hull, hvt.data(), nvert3 * sizeof(T), hipMemcpyHostToDevice));
     HIP_OK(hipMalloc((void **)&h->d_eadr, neadr * sizeof(int)));
     HIP_OK(hipMemcpy(h->d_eadr, b.i32("mj_hull_eadr", 0), neadr * sizeof(int), hipMemcpyHostToDevice));
     HIP_OK(hipMalloc((void **)&h->d_edge, nedge * sizeof(int)));
     HIP_OK(hipMemcpy(h->d_edge, b.i32("mj_hull_edge", 0), nedge * sizeof(int), hipMemcpyHostToDevice));
+    const uint32_t nbox6 = b.count("mj_chunk_box");
+    const double *bx = b.f64("mj_chunk_box", 0);
+    std::vector<T> bxt(nbox6);
+    for (uint32_t i = 0; i < nbox6; i++) bxt[i] = (T)bx[i];
+    // boxes must bound the vertices AFTER conversion to T: widen the half extents by one rounding step
+    if (sizeof(T) == 4) for (uint32_t i = 0; i < nbox6; i++) if (i % 6 >= 3) bxt[i] = bxt[i] * (T)1.00001 + (T)1e-7;
+    HIP_OK(hipMalloc(&h->d_box, nbox6 * sizeof(T)));
+    HIP_OK(hipMemcpy(h->d_box, bxt.data(), nbox6 * sizeof(T), hipMemcpyHostToDevice));
     HIP_OK(hipMalloc(&h->d_model, sizeof(DevModel<T>)));
   }
   static thread_local DevModel<T> m;
@@ -401,7 +414,7 @@ int tsidb_destroy(tsidb_handle h) {
   if (!h) return -1;
   if (h->d_model) {
     (void)hipSetDevice(h->device);
-    (void)hipFree(h->d_model); (void)hipFree(h->d_hull); (void)hipFree(h->d_eadr); (void)hipFree(h->d_edge);
+    (void)hipFree(h->d_model); (void)hipFree(h->d_hull); (void)hipFree(h->d_box); (void)hipFree(h->d_eadr); (void)hipFree(h->d_edge);
   }
   delete h;
   return 0;

@@ -8,8 +8,15 @@
 // diagnostic build only (tools/stamp_profile.py): shader-clock stamps per phase, never in the product .so
 __device__ unsigned long long g_stamp[8192][32];
 #define TSIDB_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 8192) g_stamp[blockIdx.x][k] = __builtin_amdgcn_s_memtime(); } while (0)
+// accumulate the time since the previous TSIDB_LAP into slot k (for phases inside loops)
+#define TSIDB_LAP_INIT() unsigned long long lap_t_ = __builtin_amdgcn_s_memtime()
+#define TSIDB_LAP(k) do { unsigned long long n_ = __builtin_amdgcn_s_memtime(); if (threadIdx.x == 0 && blockIdx.x < 8192) g_stamp[blockIdx.x][k] += n_ - lap_t_; lap_t_ = n_; } while (0)
+#define TSIDB_LAP_ZERO(k) do { if (threadIdx.x == 0 && blockIdx.x < 8192) g_stamp[blockIdx.x][k] = 0; } while (0)
 #else
 #define TSIDB_STAMP(k) do { } while (0)
+#define TSIDB_LAP_INIT() do { } while (0)
+#define TSIDB_LAP(k) do { } while (0)
+#define TSIDB_LAP_ZERO(k) do { } while (0)
 #endif
 
 namespace tsidb {
@@ -72,7 +79,9 @@ struct DevModel {
   T opt[7];
   T contact[8];
   T meaninertia;
-  const T *hull_vert;  // [nvert][3] body frame (device pointer)
+  const T *hull_x, *hull_y, *hull_z; // hull vertices, body frame, struct-of-arrays [nvert] each (device)
+  int chunk_adr[NB + 1];             // 64-vertex spatial chunks per hull (k-d order) ...
+  const T *chunk_box;                // ... with boxes [nchunk][6] = centre xyz, half extent xyz (device)
   const int *hull_eadr, *hull_edge;
 };
 
@@ -108,16 +117,56 @@ template <typename T> struct Eps;
 template <> struct Eps<double> { static constexpr double v = 2.220446049250313e-16; static constexpr double inf = 1e300; };
 template <> struct Eps<float> { static constexpr float v = 1.1920929e-07f; static constexpr float inf = 1e30f; };
 
-// wavefront reductions over 64 lanes (shuffles; no LDS)
+// wavefront reductions over 64 lanes on the VALU (DPP row ops + row broadcasts; no LDS crossbar):
+// quad xor-1, quad xor-2, row_half_mirror, row_mirror give every lane its 16-lane row total; row_bcast15
+// / row_bcast31 fold the four rows into lane 63, which v_readlane broadcasts.
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ float dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, true));
+}
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ double dpp_mov(double v) {
+  const long long b = __builtin_bit_cast(long long, v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffLL), CTRL, ROW_MASK, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, ROW_MASK, 0xf, true);
+  return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ float lane63(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+__device__ __forceinline__ double lane63(double v) {
+  const long long b = __builtin_bit_cast(long long, v);
+  const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffLL), 63), hi = __builtin_amdgcn_readlane((int)(b >> 32), 63);
+  return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
 template <typename T> __device__ __forceinline__ T wave_sum(T v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
-  return v;
+  v += dpp_mov<0xB1, 0xf>(v);  // quad_perm [1,0,3,2]
+  v += dpp_mov<0x4E, 0xf>(v);  // quad_perm [2,3,0,1]
+  v += dpp_mov<0x141, 0xf>(v); // row_half_mirror
+  v += dpp_mov<0x140, 0xf>(v); // row_mirror
+  v += dpp_mov<0x142, 0xa>(v); // row_bcast15 into rows 1, 3
+  v += dpp_mov<0x143, 0xc>(v); // row_bcast31 into rows 2, 3
+  return lane63(v);
+}
+template <int CTRL, int ROW_MASK, typename T> __device__ __forceinline__ T dpp_min_step(T v) {
+  // lanes a disabled row would leave at 0 must not win the min: feed the lane's own value instead
+  T w;
+  if constexpr (sizeof(T) == 4) {
+    w = __builtin_bit_cast(T, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
+  } else {
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_update_dpp((int)(b & 0xffffffffLL), (int)(b & 0xffffffffLL), CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp((int)(b >> 32), (int)(b >> 32), CTRL, ROW_MASK, 0xf, false);
+    w = __builtin_bit_cast(T, ((long long)hi << 32) | (unsigned int)lo);
+  }
+  return w < v ? w : v;
 }
 template <typename T> __device__ __forceinline__ T wave_min(T v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) { T w = __shfl_xor(v, o, WAVE); v = w < v ? w : v; }
-  return v;
+  v = dpp_min_step<0xB1, 0xf>(v);
+  v = dpp_min_step<0x4E, 0xf>(v);
+  v = dpp_min_step<0x141, 0xf>(v);
+  v = dpp_min_step<0x140, 0xf>(v);
+  v = dpp_min_step<0x142, 0xa>(v);
+  v = dpp_min_step<0x143, 0xc>(v);
+  return lane63(v);
 }
 // (value, index) lexicographic minimum: smallest value, lowest index among equals
 template <typename T> __device__ __forceinline__ void wave_argmin(T &v, int &i) {

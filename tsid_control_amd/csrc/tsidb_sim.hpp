@@ -30,6 +30,7 @@ struct SimLds {
   T qpos[NQ], qvel[NV], ctrl[NA];
   T qfs[NV], qas[NV], qacc[NV], bias[NV], xv[NV], yv[NV];
   int cbody[MAXCON], cvert[MAXCON];
+  unsigned anc[NB]; // ancestor bitmask per body (copied from the model: LDS latency, not global)
   T cr[MAXCON][3], cdist[MAXCON], cfv[MAXCON][3]; // contact point (rel O), distance, force vector
 };
 
@@ -43,32 +44,35 @@ __device__ __forceinline__ int sym_idx(int i, int j) { // packed upper index of 
 template <typename T>
 __device__ __forceinline__ T chol26_solve(T (&a)[NV], T rhs, int lane, bool &spd) {
   spd = true;
+  T rd[NV]; // 1 / L[k][k], wave-uniform
 #pragma unroll
   for (int k = 0; k < NV; k++) {
     const T akk = rdlane(a[k], k);
     if (!(akk > 0)) spd = false;
-    const T lkk = sqrt(akk > 0 ? akk : T(1));
-    const T lik = lane == k ? lkk : a[k] / lkk;
+    const T rk = rsqrt_t(akk > 0 ? akk : T(1));
+    rd[k] = rk;
+    const T lik = lane == k ? akk * rk : a[k] * rk;
     a[k] = lik;
 #pragma unroll
     for (int j = k + 1; j < NV; j++) a[j] -= lik * rdlane(lik, j);
   }
-  T acc = rhs, yv = 0;
-#pragma unroll
-  for (int k = 0; k < NV; k++) {
-    const T yk = rdlane(acc, k) / rdlane(a[k], k);
-    if (lane == k) yv = yk;
-    acc -= a[k] * yk;
-  }
-  T xr[NV], x = 0;
+  // y = L^-1 rhs (uniform chain, lane k contributes y_k) fused with X = L^-1 e_lane (column `lane`)
+  T acc = rhs, yv = 0, xr[NV], x = 0;
 #pragma unroll
   for (int i = 0; i < NV; i++) {
-    T sacc = lane == i ? T(1) : T(0);
+    T s0 = lane == i ? T(1) : T(0), s1 = 0;
 #pragma unroll
-    for (int k = 0; k < i; k++) sacc -= rdlane(a[k], i) * xr[k];
-    xr[i] = sacc / rdlane(a[i], i);
-    x += xr[i] * rdlane(yv, i);
+    for (int k = 0; k < i; k++) {
+      const T lik = rdlane(a[k], i);
+      if (k & 1) s1 -= lik * xr[k]; else s0 -= lik * xr[k];
+    }
+    xr[i] = (s0 + s1) * rd[i];
+    const T yi = rdlane(acc, i) * rd[i];
+    if (lane == i) yv = yi;
+    acc -= a[i] * yi;
   }
+#pragma unroll
+  for (int i = 0; i < NV; i++) x += xr[i] * rdlane(yv, i);
   return x;
 }
 
@@ -84,8 +88,10 @@ template <typename T> __device__ __forceinline__ T mulM(const SimLds<T> &L, cons
 template <typename T>
 __device__ __forceinline__ void contact_rows(const DevModel<T> &m, const SimLds<T> &L, int c, const T *x, T mu, T *out) {
   T tw[6] = {0, 0, 0, 0, 0, 0};
-  for (int a = L.cbody[c]; a >= 0; a = m.mj_parent[a]) {
+  for (unsigned mk = L.anc[L.cbody[c]]; mk; mk &= mk - 1) {
+    const int a = __ffs(mk) - 1;
     if (a == 0) {
+#pragma unroll
       for (int k = 0; k < 6; k++) {
         const T xk = x[k];
 #pragma unroll
@@ -161,102 +167,136 @@ __device__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L, int lane, const
   __syncthreads();
   const T Oz = L.qpos[2];
 
-  // ---- kinematics, velocities, bias accelerations, body forces (by tree depth)
-  for (int dpt = 0; dpt <= m.mj_maxdepth; dpt++) {
-    if (lane < NB && m.mj_depth[lane] == dpt) {
-      const int b = lane;
-      T Rb[9], pb[3], Vb[6], Ab[6];
-      if (b == 0) {
-        quat_to_R(L.qpos[4], L.qpos[5], L.qpos[6], L.qpos[3], Rb); // wxyz storage
-        pb[0] = pb[1] = pb[2] = 0;
+  // ---- kinematics, velocities, bias accelerations: parent-independent work up front, the depth
+  //      loop carries R, p, V, A down the tree, body inertias/forces in one parallel pass
+  T Rb[9], pb[3], Vb[6], Ab[6], Rl[9], qd = 0;
+  const int mydepth = lane < NB ? m.mj_depth[lane] : -1;
+  const int mypar = lane < NB ? m.mj_parent[lane] : 0;
+  const int mynchild = lane < NB ? m.mj_nchild[lane] : 0;
+  int mychild[MAXCHILD];
 #pragma unroll
-        for (int k = 0; k < 3; k++) {
+  for (int ci = 0; ci < MAXCHILD; ci++) mychild[ci] = lane < NB ? m.mj_child[lane][ci] : 0;
+  const unsigned dofanc = lane < NV ? m.mj_anc[lane < 6 ? 0 : lane - 5] : 0u;
+  if (lane < NB) L.anc[lane] = m.mj_anc[lane];
 #pragma unroll
-          for (int i = 0; i < 3; i++) {
-            L.S[k][i] = (i == k) ? T(1) : T(0); L.S[k][3 + i] = 0;        // world-frame linear dofs
-            L.S[3 + k][i] = 0; L.S[3 + k][3 + i] = Rb[3 * i + k];          // body-frame angular dofs
-          }
-        }
-        T wl[3] = {L.qvel[3], L.qvel[4], L.qvel[5]};
-        Vb[0] = L.qvel[0]; Vb[1] = L.qvel[1]; Vb[2] = L.qvel[2];
-        mat3vec(Rb, wl, Vb + 3);
-        // dS/dt = V x S for the body-fixed angular axes, 0 for the world-fixed linear ones
+  for (int i = 0; i < 6; i++) { Vb[i] = 0; Ab[i] = 0; }
 #pragma unroll
-        for (int i = 0; i < 6; i++) Ab[i] = 0;
+  for (int i = 0; i < 3; i++) pb[i] = 0;
+  if (lane == 0) {
+    quat_to_R(L.qpos[4], L.qpos[5], L.qpos[6], L.qpos[3], Rb); // wxyz storage
 #pragma unroll
-        for (int k = 0; k < 3; k++) {
-          T Sk[6] = {0, 0, 0, Rb[k], Rb[3 + k], Rb[6 + k]}, dS[6];
-          cross_mm(Vb, Sk, dS);
+    for (int k = 0; k < 3; k++) {
 #pragma unroll
-          for (int i = 0; i < 6; i++) Ab[i] += dS[i] * wl[k];
-        }
-      } else {
-        const int p = m.mj_parent[b];
-        T Rq[9], th = L.qpos[6 + b], c = cos(th), s = sin(th);
-        mat3mul(L.R[p], m.mj_R[b], Rq);
-#pragma unroll
-        for (int i = 0; i < 3; i++) {
-          Rb[3 * i + 0] = c * Rq[3 * i] + s * Rq[3 * i + 1];
-          Rb[3 * i + 1] = -s * Rq[3 * i] + c * Rq[3 * i + 1];
-          Rb[3 * i + 2] = Rq[3 * i + 2];
-        }
-        mat3vec(L.R[p], m.mj_pos[b], pb);
-#pragma unroll
-        for (int i = 0; i < 3; i++) pb[i] += L.p[p][i];
-        T Sj[6], a[3] = {Rb[2], Rb[5], Rb[8]}, vxs[6];
-        cross3(pb, a, Sj);
-        Sj[3] = a[0]; Sj[4] = a[1]; Sj[5] = a[2];
-        const T qd = L.qvel[5 + b];
-        cross_mm(L.V[p], Sj, vxs);
-#pragma unroll
-        for (int i = 0; i < 6; i++) {
-          L.S[5 + b][i] = Sj[i];
-          Vb[i] = L.V[p][i] + Sj[i] * qd;
-          Ab[i] = L.A[p][i] + vxs[i] * qd;
-        }
+      for (int i = 0; i < 3; i++) {
+        L.S[k][i] = (i == k) ? T(1) : T(0); L.S[k][3 + i] = 0;        // world-frame linear dofs
+        L.S[3 + k][i] = 0; L.S[3 + k][3 + i] = Rb[3 * i + k];          // body-frame angular dofs
       }
-      const T *Yb = m.mj_inertia[b];
-      T cw[3], I[9] = {Yb[4], Yb[5], Yb[6], Yb[5], Yb[7], Yb[8], Yb[6], Yb[8], Yb[9]}, Tm[9], RT[9];
-      mat3vec(Rb, Yb + 1, cw);
+    }
+    T wl[3] = {L.qvel[3], L.qvel[4], L.qvel[5]};
+    Vb[0] = L.qvel[0]; Vb[1] = L.qvel[1]; Vb[2] = L.qvel[2];
+    mat3vec(Rb, wl, Vb + 3);
+    // dS/dt = V x S for the body-fixed angular axes, 0 for the world-fixed linear ones
 #pragma unroll
-      for (int i = 0; i < 3; i++) cw[i] += pb[i];
-      mat3mul(Rb, I, Tm);
+    for (int k = 0; k < 3; k++) {
+      T Sk[6] = {0, 0, 0, Rb[k], Rb[3 + k], Rb[6 + k]}, dS[6];
+      cross_mm(Vb, Sk, dS);
 #pragma unroll
-      for (int i = 0; i < 3; i++)
+      for (int i = 0; i < 6; i++) Ab[i] += dS[i] * wl[k];
+    }
 #pragma unroll
-        for (int k = 0; k < 3; k++) RT[3 * i + k] = Rb[3 * k + i];
-      mat3mul(Tm, RT, I);
-      const T mass = Yb[0], c2 = dot3(cw, cw);
-      T Y[10];
-      Y[0] = mass; Y[1] = mass * cw[0]; Y[2] = mass * cw[1]; Y[3] = mass * cw[2];
-      Y[4] = I[0] + mass * (c2 - cw[0] * cw[0]); Y[5] = I[1] - mass * cw[0] * cw[1]; Y[6] = I[2] - mass * cw[0] * cw[2];
-      Y[7] = I[4] + mass * (c2 - cw[1] * cw[1]); Y[8] = I[5] - mass * cw[1] * cw[2];
-      Y[9] = I[8] + mass * (c2 - cw[2] * cw[2]);
-      T Ag[6] = {Ab[0], Ab[1], Ab[2] - gz, Ab[3], Ab[4], Ab[5]}, Ya[6], Yv[6], vx[6];
-      yo_mul(Y, Ag, Ya);
-      yo_mul(Y, Vb, Yv);
-      cross_mf(Vb, Yv, vx);
+    for (int i = 0; i < 9; i++) L.R[0][i] = Rb[i];
+#pragma unroll
+    for (int i = 0; i < 3; i++) L.p[0][i] = 0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) { L.V[0][i] = Vb[i]; L.A[0][i] = Ab[i]; }
+  } else if (lane < NB) {
+    const T *Rq = m.mj_R[lane];
+    const T th = L.qpos[6 + lane], c = cos(th), s = sin(th);
+    qd = L.qvel[5 + lane];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      Rl[3 * i + 0] = c * Rq[3 * i] + s * Rq[3 * i + 1];
+      Rl[3 * i + 1] = -s * Rq[3 * i] + c * Rq[3 * i + 1];
+      Rl[3 * i + 2] = Rq[3 * i + 2];
+    }
+  }
+  __syncthreads();
+  for (int dpt = 1; dpt <= m.mj_maxdepth; dpt++) {
+    if (mydepth == dpt) {
+      const int b = lane, p = mypar;
+      mat3mul(L.R[p], Rl, Rb);
+      mat3vec(L.R[p], m.mj_pos[b], pb);
+#pragma unroll
+      for (int i = 0; i < 3; i++) pb[i] += L.p[p][i];
+      T Sj[6], a[3] = {Rb[2], Rb[5], Rb[8]}, vxs[6];
+      cross3(pb, a, Sj);
+      Sj[3] = a[0]; Sj[4] = a[1]; Sj[5] = a[2];
+      cross_mm(L.V[p], Sj, vxs);
+#pragma unroll
+      for (int i = 0; i < 6; i++) {
+        L.S[5 + b][i] = Sj[i];
+        Vb[i] = L.V[p][i] + Sj[i] * qd;
+        Ab[i] = L.A[p][i] + vxs[i] * qd;
+        L.V[b][i] = Vb[i]; L.A[b][i] = Ab[i];
+      }
 #pragma unroll
       for (int i = 0; i < 9; i++) L.R[b][i] = Rb[i];
 #pragma unroll
       for (int i = 0; i < 3; i++) L.p[b][i] = pb[i];
-#pragma unroll
-      for (int i = 0; i < 6; i++) { L.V[b][i] = Vb[i]; L.A[b][i] = Ab[i]; L.f[b][i] = Ya[i] + vx[i]; }
-#pragma unroll
-      for (int i = 0; i < 10; i++) { L.Y[b][i] = Y[i]; L.Yc[b][i] = Y[i]; }
     }
     __syncthreads();
   }
+  if (lane < NB) {
+    const int b = lane;
+    const T *Yb = m.mj_inertia[b];
+    T cw[3], I[9] = {Yb[4], Yb[5], Yb[6], Yb[5], Yb[7], Yb[8], Yb[6], Yb[8], Yb[9]}, Tm[9], RT[9];
+    mat3vec(Rb, Yb + 1, cw);
+#pragma unroll
+    for (int i = 0; i < 3; i++) cw[i] += pb[i];
+    mat3mul(Rb, I, Tm);
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+      for (int k = 0; k < 3; k++) RT[3 * i + k] = Rb[3 * k + i];
+    mat3mul(Tm, RT, I);
+    const T mass = Yb[0], c2 = dot3(cw, cw);
+    T Y[10];
+    Y[0] = mass; Y[1] = mass * cw[0]; Y[2] = mass * cw[1]; Y[3] = mass * cw[2];
+    Y[4] = I[0] + mass * (c2 - cw[0] * cw[0]); Y[5] = I[1] - mass * cw[0] * cw[1]; Y[6] = I[2] - mass * cw[0] * cw[2];
+    Y[7] = I[4] + mass * (c2 - cw[1] * cw[1]); Y[8] = I[5] - mass * cw[1] * cw[2];
+    Y[9] = I[8] + mass * (c2 - cw[2] * cw[2]);
+    T Ag[6] = {Ab[0], Ab[1], Ab[2] - gz, Ab[3], Ab[4], Ab[5]}, Ya[6], Yv[6], vx[6];
+    yo_mul(Y, Ag, Ya);
+    yo_mul(Y, Vb, Yv);
+    cross_mf(Vb, Yv, vx);
+#pragma unroll
+    for (int i = 0; i < 6; i++) L.f[b][i] = Ya[i] + vx[i];
+#pragma unroll
+    for (int i = 0; i < 10; i++) { L.Y[b][i] = Y[i]; L.Yc[b][i] = Y[i]; }
+  }
+  __syncthreads();
   for (int dpt = m.mj_maxdepth - 1; dpt >= 0; dpt--) {
-    if (lane < NB && m.mj_depth[lane] == dpt) {
+    if (mydepth == dpt && mynchild > 0) {
       const int b = lane;
-      for (int ci = 0; ci < m.mj_nchild[b]; ci++) {
-        const int c = m.mj_child[b][ci];
+      T fa[6], ya[10];
 #pragma unroll
-        for (int i = 0; i < 6; i++) L.f[b][i] += L.f[c][i];
+      for (int i = 0; i < 6; i++) fa[i] = L.f[b][i];
 #pragma unroll
-        for (int i = 0; i < 10; i++) L.Yc[b][i] += L.Yc[c][i];
+      for (int i = 0; i < 10; i++) ya[i] = L.Yc[b][i];
+#pragma unroll
+      for (int ci = 0; ci < MAXCHILD; ci++) {
+        if (ci < mynchild) {
+          const int c = mychild[ci];
+#pragma unroll
+          for (int i = 0; i < 6; i++) fa[i] += L.f[c][i];
+#pragma unroll
+          for (int i = 0; i < 10; i++) ya[i] += L.Yc[c][i];
+        }
       }
+#pragma unroll
+      for (int i = 0; i < 6; i++) L.f[b][i] = fa[i];
+#pragma unroll
+      for (int i = 0; i < 10; i++) L.Yc[b][i] = ya[i];
     }
     __syncthreads();
   }
@@ -269,25 +309,17 @@ __device__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L, int lane, const
     for (int i = 0; i < 6; i++) { Sk[i] = L.S[k][i]; hk += Sk[i] * L.f[bk][i]; }
     L.bias[k] = hk;
     yo_mul(L.Yc[bk], Sk, Fk);
-    int a = bk;
-    while (true) {
-      if (a == 0) {
-        for (int i = 0; i < 6 && i <= k; i++) {
-          T val = 0;
+    for (unsigned mk = dofanc; mk; mk &= mk - 1) {
+      const int a = __ffs(mk) - 1;
+      const int i0 = a == 0 ? 0 : 5 + a, i1 = a == 0 ? 5 : 5 + a;
+      for (int i = i0; i <= i1; i++) {
+        if (i > k) continue;
+        T val = 0;
 #pragma unroll
-          for (int e = 0; e < 6; e++) val += L.S[i][e] * Fk[e];
-          L.M[i * LDM + k] = val;
-          L.M[k * LDM + i] = val;
-        }
-        break;
+        for (int e = 0; e < 6; e++) val += L.S[i][e] * Fk[e];
+        L.M[i * LDM + k] = val;
+        L.M[k * LDM + i] = val;
       }
-      const int i = 5 + a;
-      T val = 0;
-#pragma unroll
-      for (int e = 0; e < 6; e++) val += L.S[i][e] * Fk[e];
-      L.M[i * LDM + k] = val;
-      L.M[k * LDM + i] = val;
-      a = m.mj_parent[a];
     }
     qfs = -hk;
   }
@@ -320,21 +352,53 @@ __device__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L, int lane, const
     if (zc - m.rbound[b][3] > margin) continue;
     const int v0 = m.hull_adr[b], v1 = m.hull_adr[b + 1];
     const T r6 = Rb[6], r7 = Rb[7], r8 = Rb[8];
+    // exact pruned support search: the hull's vertices are stored in k-d order, 64 per chunk, each
+    // chunk with a bounding box.  A chunk can hold the lowest vertex (or one within the tie
+    // tolerance of it) only if the box's lower bound along the floor normal does not exceed the best
+    // z found so far; every such chunk is scanned, so the result equals the exhaustive search.
+    const int c0 = m.chunk_adr[b], nch = m.chunk_adr[b + 1] - c0;
+    T zlb = INF;
+    if (lane < nch) {
+      const T *bx = m.chunk_box + 6 * (c0 + lane);
+      zlb = r6 * bx[0] + r7 * bx[1] + r8 * bx[2] + pz - (fabs(r6) * bx[3] + fabs(r7) * bx[4] + fabs(r8) * bx[5]);
+      zlb -= fabs(zlb) * T(4) * Eps<T>::v; // rounding slack: never prune a chunk that could matter
+    }
+    unsigned long long scanned = 0;
     T zmin = INF;
-    for (int i = v0 + lane; i < v1; i += WAVE) {
-      const T *vv = m.hull_vert + 3 * i;
-      const T z = r6 * vv[0] + r7 * vv[1] + r8 * vv[2] + pz;
-      zmin = z < zmin ? z : zmin;
+    T zmine = 0; // this lane's vertex z in the chunk being scanned
+    {
+      T zl = zlb;
+      int ci = lane;
+      wave_argmin(zl, ci);
+      unsigned long long pend = 1ull << ci;
+      while (pend) {
+        const int c = __ffsll((long long)pend) - 1;
+        const int i = v0 + WAVE * c + lane;
+        T z = INF;
+        if (i < v1) z = r6 * m.hull_x[i] + r7 * m.hull_y[i] + r8 * m.hull_z[i] + pz;
+        const T zc2 = wave_min(z);
+        zmin = zc2 < zmin ? zc2 : zmin;
+        scanned |= 1ull << c;
+        pend = __ballot(lane < nch && zlb <= zmin + tie_tol) & ~scanned;
+      }
     }
-    zmin = wave_min(zmin);
+    (void)zmine;
     if (zmin > margin) continue;
+    // lowest-index vertex within the tie tolerance of the minimum (chunks are in index order)
     int best = 0x7fffffff;
-    for (int i = v0 + lane; i < v1 && best == 0x7fffffff; i += WAVE) {
-      const T *vv = m.hull_vert + 3 * i;
-      const T z = r6 * vv[0] + r7 * vv[1] + r8 * vv[2] + pz;
-      if (z <= zmin + tie_tol) best = i;
+    {
+      const T zt = zmin + tie_tol;
+      for (unsigned long long sm = scanned; sm && best == 0x7fffffff; sm &= sm - 1) {
+        const int c = __ffsll((long long)sm) - 1;
+        const int i = v0 + WAVE * c + lane;
+        int cand = 0x7fffffff;
+        if (i < v1) {
+          const T z = r6 * m.hull_x[i] + r7 * m.hull_y[i] + r8 * m.hull_z[i] + pz;
+          if (z <= zt) cand = i;
+        }
+        best = wave_min_int(cand);
+      }
     }
-    best = wave_min_int(best);
     const int e0 = m.hull_eadr[best];
     int nnb = m.hull_eadr[best + 1] - e0;
     nnb = nnb > WAVE - 1 ? WAVE - 1 : nnb;
@@ -343,7 +407,7 @@ __device__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L, int lane, const
     int vid = best;
     if (lane <= nnb) {
       if (lane > 0) vid = v0 + m.hull_edge[e0 + lane - 1];
-      const T *vv = m.hull_vert + 3 * vid;
+      const T vv[3] = {m.hull_x[vid], m.hull_y[vid], m.hull_z[vid]};
       mat3vec(Rb, vv, w);
       w[0] += L.p[b][0]; w[1] += L.p[b][1]; w[2] += pz;
       keep = lane == 0 || w[2] <= margin;
@@ -444,6 +508,8 @@ __device__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L, int lane, const
     const T scale = T(1) / (m.meaninertia * NV);
     T cost = 0;
     int iter = 0;
+    TSIDB_LAP_ZERO(24); TSIDB_LAP_ZERO(25); TSIDB_LAP_ZERO(26); TSIDB_LAP_ZERO(27); TSIDB_LAP_ZERO(28);
+    TSIDB_LAP_INIT();
     while (true) {
       // ---- constraint state at the current point: forces, active rows, cost
       rows_eval(rs, T(0), cc, gg, hh);
@@ -485,7 +551,7 @@ __device__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L, int lane, const
         const int k = lane, bk = k < 6 ? 0 : k - 5;
         T s = 0;
         for (int c = 0; c < ncon; c++) {
-          if (!((m.mj_anc[L.cbody[c]] >> bk) & 1u)) continue;
+          if (!((L.anc[L.cbody[c]] >> bk) & 1u)) continue;
           T rxf[3];
           cross3(L.cr[c], L.cfv[c], rxf);
           s += L.S[k][0] * L.cfv[c][0] + L.S[k][1] * L.cfv[c][1] + L.S[k][2] * L.cfv[c][2] +
@@ -501,6 +567,7 @@ __device__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L, int lane, const
       }
       cost = newcost;
       if (iter >= maxiter) break;
+      TSIDB_LAP(24);
       // ---- Newton Hessian H = M + J^T D J: CRB recursion on the per-body contact inertia
       if (rs.has_c) {
         // W = [A, -A [r]x ; [r]x A, -[r]x A [r]x] with [r]x the cross matrix of the contact point
@@ -524,26 +591,31 @@ __device__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L, int lane, const
 #pragma unroll
           for (int j = 0; j < 3; j++) L.Wc[lane][sym_idx(i, 3 + j)] = XA[3 * j + i];
       }
+      for (int i = lane; i < NB * 21; i += WAVE) (&L.K[0][0])[i] = 0;
       __syncthreads();
-      for (int idx = lane; idx < NB * 21; idx += WAVE) {
-        const int b = idx / 21, e = idx % 21;
-        T s = 0;
-        for (int c = 0; c < ncon; c++)
-          if (L.cbody[c] == b) s += L.Wc[c][e];
-        L.K[b][e] = s;
-      }
-      __syncthreads();
-      for (int dpt = m.mj_maxdepth - 1; dpt >= 0; dpt--) {
-        if (lane < NB && m.mj_depth[lane] == dpt)
-          for (int ci = 0; ci < m.mj_nchild[lane]; ci++) {
-            const int c = m.mj_child[lane][ci];
-            for (int e = 0; e < 21; e++) L.K[lane][e] += L.K[c][e];
+      // composite contact inertia: contacts arrive grouped by body; lane e sums entry e of the group
+      // and pushes it to every ancestor of that body (subtree sums without a depth loop)
+      unsigned touched = 0;
+      {
+        T accK = 0;
+        for (int c = 0; c < ncon; c++) {
+          const int b = L.cbody[c];
+          if (lane < 21) accK += L.Wc[c][lane];
+          if (c + 1 == ncon || L.cbody[c + 1] != b) {
+            const unsigned am = L.anc[b];
+            for (unsigned mk = am; mk; mk &= mk - 1) {
+              const int a = __ffs(mk) - 1;
+              if (lane < 21) L.K[a][lane] += accK;
+            }
+            touched |= am;
+            accK = 0;
           }
-        __syncthreads();
+        }
       }
+      __syncthreads();
       for (int i = lane; i < NV * LDM; i += WAVE) L.H[i] = L.M[i];
       __syncthreads();
-      if (lane < NV) {
+      if (lane < NV && ((touched >> (lane < 6 ? 0 : lane - 5)) & 1u)) {
         const int k = lane, bk = k < 6 ? 0 : k - 5;
         T G[6];
 #pragma unroll
@@ -553,27 +625,28 @@ __device__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L, int lane, const
           for (int j = 0; j < 6; j++) s += L.K[bk][sym_idx(i, j)] * L.S[k][j];
           G[i] = s;
         }
-        int a = bk;
-        while (true) {
+        for (unsigned mk = dofanc; mk; mk &= mk - 1) {
+          const int a = __ffs(mk) - 1;
           const int i0 = a == 0 ? 0 : 5 + a, i1 = a == 0 ? 5 : 5 + a;
-          for (int i = i0; i <= i1 && i <= k; i++) {
+          for (int i = i0; i <= i1; i++) {
+            if (i > k) continue;
             T val = 0;
 #pragma unroll
             for (int e = 0; e < 6; e++) val += L.S[i][e] * G[e];
             L.H[i * LDM + k] += val;
             if (i != k) L.H[k * LDM + i] += val;
           }
-          if (a == 0) break;
-          a = m.mj_parent[a];
         }
-        if (fact) L.H[k * LDM + k] += rs.fD;
       }
+      if (fact) L.H[lane * LDM + lane] += rs.fD;
       __syncthreads();
+      TSIDB_LAP(25);
 #pragma unroll
       for (int j = 0; j < NV; j++) arow[j] = lane < NV ? L.H[lane * LDM + j] : T(0);
       bool ok;
       const T search = -chol26_solve(arow, grad, lane, ok);
       if (!ok) { fail |= 2; break; }
+      TSIDB_LAP(26);
       // ---- exact line search along `search`
       stage(search);
       const T Mv = mulM(L, L.xv, lane);
@@ -610,6 +683,7 @@ __device__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L, int lane, const
         for (int i = 0; i < 4; i++) rs.cjar[i] += alpha * rs.cJv[i];
       }
       iter++;
+      TSIDB_LAP(27);
     }
     solver_iter = iter;
   }

@@ -70,95 +70,129 @@ __device__ void rbd_terms(const DevModel<T> &m, TickLds<T> &L, int lane) {
   KinScratch<T> &K = L.k;
   const T GZ = T(9.81);
   for (int i = lane; i < NV * LDD; i += WAVE) L.Dyn[i] = 0;
-  // ---- forward pass by tree depth
-  for (int dpt = 0; dpt <= m.pin_maxdepth; dpt++) {
-    if (lane < NJ && m.pin_depth[lane] == dpt) {
-      const int j = lane;
-      T Rj[9], pj[3], Vj[6], Aj[6];
-      if (j == 0) {
-        quat_to_R(L.qs[3], L.qs[4], L.qs[5], L.qs[6], Rj);
-        pj[0] = pj[1] = pj[2] = 0;
-        mat3vec(Rj, &L.vs[0], Vj);
-        mat3vec(Rj, &L.vs[3], Vj + 3);
+  // ---- forward pass.  Everything that does not depend on the parent (sin/cos, the joint's local
+  //      rotation) is computed once up front; the depth loop carries only R, p, V, A down the tree;
+  //      body inertias and forces follow in one parallel pass.
+  T Rj[9], pj[3], Vj[6], Aj[6], Rl[9], qd = 0;
+  // topology into registers up front: no dependent global loads inside the tree passes
+  const int mydepth = lane < NJ ? m.pin_depth[lane] : -1;
+  const int mypar = lane < NJ ? m.pin_parent[lane] : 0;
+  const int mynchild = lane < NJ ? m.pin_nchild[lane] : 0;
+  int mychild[MAXCHILD];
 #pragma unroll
-        for (int i = 0; i < 6; i++) Aj[i] = 0;
+  for (int ci = 0; ci < MAXCHILD; ci++) mychild[ci] = lane < NJ ? m.pin_child[lane][ci] : 0;
+  const unsigned dofanc = lane < NV ? m.pin_anc[lane < 6 ? 0 : lane - 5] : 0u; // ancestors of this dof's joint
 #pragma unroll
-        for (int k = 0; k < 3; k++) {
+  for (int i = 0; i < 6; i++) { Vj[i] = 0; Aj[i] = 0; }
 #pragma unroll
-          for (int i = 0; i < 3; i++) {
-            K.S[k][i] = Rj[3 * i + k]; K.S[k][3 + i] = 0;
-            K.S[3 + k][i] = 0; K.S[3 + k][3 + i] = Rj[3 * i + k];
-          }
-        }
-      } else {
-        const int p = m.pin_parent[j];
-        const T *PR = m.pin_place[j];
-        T th = L.qs[6 + j], c = cos(th), s = sin(th), Rl[9];
+  for (int i = 0; i < 3; i++) pj[i] = 0;
+  if (lane == 0) {
+    quat_to_R(L.qs[3], L.qs[4], L.qs[5], L.qs[6], Rj);
+    mat3vec(Rj, &L.vs[0], Vj);
+    mat3vec(Rj, &L.vs[3], Vj + 3);
 #pragma unroll
-        for (int i = 0; i < 3; i++) {
-          Rl[3 * i + 0] = c * PR[3 * i] + s * PR[3 * i + 1];
-          Rl[3 * i + 1] = -s * PR[3 * i] + c * PR[3 * i + 1];
-          Rl[3 * i + 2] = PR[3 * i + 2];
-        }
-        mat3mul(K.R[p], Rl, Rj);
-        mat3vec(K.R[p], PR + 9, pj);
+    for (int k = 0; k < 3; k++) {
 #pragma unroll
-        for (int i = 0; i < 3; i++) pj[i] += K.p[p][i];
-        T Sj[6], a[3] = {Rj[2], Rj[5], Rj[8]};
-        cross3(pj, a, Sj);
-        Sj[3] = a[0]; Sj[4] = a[1]; Sj[5] = a[2];
-        T qd = L.vs[5 + j], vxs[6];
-        cross_mm(K.V[p], Sj, vxs);
-#pragma unroll
-        for (int i = 0; i < 6; i++) {
-          K.S[5 + j][i] = Sj[i];
-          Vj[i] = K.V[p][i] + Sj[i] * qd;
-          Aj[i] = K.A[p][i] + vxs[i] * qd;
-        }
+      for (int i = 0; i < 3; i++) {
+        K.S[k][i] = Rj[3 * i + k]; K.S[k][3 + i] = 0;
+        K.S[3 + k][i] = 0; K.S[3 + k][3 + i] = Rj[3 * i + k];
       }
-      // body inertia about O in world axes, RNEA body force (gravity as +g base acceleration)
-      const T *Yb = m.pin_inertia[j];
-      T cw[3], I[9] = {Yb[4], Yb[5], Yb[6], Yb[5], Yb[7], Yb[8], Yb[6], Yb[8], Yb[9]}, Tm[9], RT[9];
-      mat3vec(Rj, Yb + 1, cw);
+    }
 #pragma unroll
-      for (int i = 0; i < 3; i++) cw[i] += pj[i];
-      mat3mul(Rj, I, Tm);
+    for (int i = 0; i < 9; i++) K.R[0][i] = Rj[i];
 #pragma unroll
-      for (int i = 0; i < 3; i++)
+    for (int i = 0; i < 3; i++) K.p[0][i] = 0;
 #pragma unroll
-        for (int k = 0; k < 3; k++) RT[3 * i + k] = Rj[3 * k + i];
-      mat3mul(Tm, RT, I);
-      T mass = Yb[0], c2 = dot3(cw, cw), Y[10];
-      Y[0] = mass; Y[1] = mass * cw[0]; Y[2] = mass * cw[1]; Y[3] = mass * cw[2];
-      Y[4] = I[0] + mass * (c2 - cw[0] * cw[0]); Y[5] = I[1] - mass * cw[0] * cw[1]; Y[6] = I[2] - mass * cw[0] * cw[2];
-      Y[7] = I[4] + mass * (c2 - cw[1] * cw[1]); Y[8] = I[5] - mass * cw[1] * cw[2];
-      Y[9] = I[8] + mass * (c2 - cw[2] * cw[2]);
-      T Ag[6] = {Aj[0], Aj[1], Aj[2] + GZ, Aj[3], Aj[4], Aj[5]}, Ya[6], Yv[6], vx[6];
-      yo_mul(Y, Ag, Ya);
-      yo_mul(Y, Vj, Yv);
-      cross_mf(Vj, Yv, vx);
+    for (int i = 0; i < 6; i++) { K.V[0][i] = Vj[i]; K.A[0][i] = 0; }
+  } else if (lane < NJ) {
+    const T *PR = m.pin_place[lane];
+    const T th = L.qs[6 + lane], c = cos(th), s = sin(th);
+    qd = L.vs[5 + lane];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      Rl[3 * i + 0] = c * PR[3 * i] + s * PR[3 * i + 1];
+      Rl[3 * i + 1] = -s * PR[3 * i] + c * PR[3 * i + 1];
+      Rl[3 * i + 2] = PR[3 * i + 2];
+    }
+  }
+  __syncthreads();
+  for (int dpt = 1; dpt <= m.pin_maxdepth; dpt++) {
+    if (mydepth == dpt) {
+      const int j = lane, p = mypar;
+      mat3mul(K.R[p], Rl, Rj);
+      mat3vec(K.R[p], m.pin_place[j] + 9, pj);
+#pragma unroll
+      for (int i = 0; i < 3; i++) pj[i] += K.p[p][i];
+      T Sj[6], a[3] = {Rj[2], Rj[5], Rj[8]}, vxs[6];
+      cross3(pj, a, Sj);
+      Sj[3] = a[0]; Sj[4] = a[1]; Sj[5] = a[2];
+      cross_mm(K.V[p], Sj, vxs);
+#pragma unroll
+      for (int i = 0; i < 6; i++) {
+        K.S[5 + j][i] = Sj[i];
+        Vj[i] = K.V[p][i] + Sj[i] * qd;
+        Aj[i] = K.A[p][i] + vxs[i] * qd;
+        K.V[j][i] = Vj[i]; K.A[j][i] = Aj[i];
+      }
 #pragma unroll
       for (int i = 0; i < 9; i++) K.R[j][i] = Rj[i];
 #pragma unroll
       for (int i = 0; i < 3; i++) K.p[j][i] = pj[i];
-#pragma unroll
-      for (int i = 0; i < 6; i++) { K.V[j][i] = Vj[i]; K.A[j][i] = Aj[i]; K.f[j][i] = Ya[i] + vx[i]; }
-#pragma unroll
-      for (int i = 0; i < 10; i++) K.Yc[j][i] = Y[i];
     }
     __syncthreads();
   }
+  if (lane < NJ) {
+    // body inertia about O in world axes, RNEA body force (gravity as +g base acceleration)
+    const int j = lane;
+    const T *Yb = m.pin_inertia[j];
+    T cw[3], I[9] = {Yb[4], Yb[5], Yb[6], Yb[5], Yb[7], Yb[8], Yb[6], Yb[8], Yb[9]}, Tm[9], RT[9];
+    mat3vec(Rj, Yb + 1, cw);
+#pragma unroll
+    for (int i = 0; i < 3; i++) cw[i] += pj[i];
+    mat3mul(Rj, I, Tm);
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+      for (int k = 0; k < 3; k++) RT[3 * i + k] = Rj[3 * k + i];
+    mat3mul(Tm, RT, I);
+    T mass = Yb[0], c2 = dot3(cw, cw), Y[10];
+    Y[0] = mass; Y[1] = mass * cw[0]; Y[2] = mass * cw[1]; Y[3] = mass * cw[2];
+    Y[4] = I[0] + mass * (c2 - cw[0] * cw[0]); Y[5] = I[1] - mass * cw[0] * cw[1]; Y[6] = I[2] - mass * cw[0] * cw[2];
+    Y[7] = I[4] + mass * (c2 - cw[1] * cw[1]); Y[8] = I[5] - mass * cw[1] * cw[2];
+    Y[9] = I[8] + mass * (c2 - cw[2] * cw[2]);
+    T Ag[6] = {Aj[0], Aj[1], Aj[2] + GZ, Aj[3], Aj[4], Aj[5]}, Ya[6], Yv[6], vx[6];
+    yo_mul(Y, Ag, Ya);
+    yo_mul(Y, Vj, Yv);
+    cross_mf(Vj, Yv, vx);
+#pragma unroll
+    for (int i = 0; i < 6; i++) K.f[j][i] = Ya[i] + vx[i];
+#pragma unroll
+    for (int i = 0; i < 10; i++) K.Yc[j][i] = Y[i];
+  }
+  __syncthreads();
   // ---- backward gather by depth: subtree forces and composite inertias
   for (int dpt = m.pin_maxdepth - 1; dpt >= 0; dpt--) {
-    if (lane < NJ && m.pin_depth[lane] == dpt) {
+    if (mydepth == dpt && mynchild > 0) {
       const int j = lane;
-      for (int ci = 0; ci < m.pin_nchild[j]; ci++) {
-        const int c = m.pin_child[j][ci];
+      T fa[6], ya[10];
 #pragma unroll
-        for (int i = 0; i < 6; i++) K.f[j][i] += K.f[c][i];
+      for (int i = 0; i < 6; i++) fa[i] = K.f[j][i];
 #pragma unroll
-        for (int i = 0; i < 10; i++) K.Yc[j][i] += K.Yc[c][i];
+      for (int i = 0; i < 10; i++) ya[i] = K.Yc[j][i];
+#pragma unroll
+      for (int ci = 0; ci < MAXCHILD; ci++) {
+        if (ci < mynchild) {
+          const int c = mychild[ci];
+#pragma unroll
+          for (int i = 0; i < 6; i++) fa[i] += K.f[c][i];
+#pragma unroll
+          for (int i = 0; i < 10; i++) ya[i] += K.Yc[c][i];
+        }
       }
+#pragma unroll
+      for (int i = 0; i < 6; i++) K.f[j][i] = fa[i];
+#pragma unroll
+      for (int i = 0; i < 10; i++) K.Yc[j][i] = ya[i];
     }
     __syncthreads();
   }
@@ -179,25 +213,18 @@ __device__ void rbd_terms(const DevModel<T> &m, TickLds<T> &L, int lane) {
     L.Jcom[0 * LDF + k] = Fk[0] * invm;
     L.Jcom[1 * LDF + k] = Fk[1] * invm;
     L.Jcom[2 * LDF + k] = Fk[2] * invm;
-    int a = jk;
-    while (true) {
-      if (a == 0) {
-        for (int i = 0; i < 6 && i <= k; i++) {
-          T val = 0;
+    // M[i][k] = S_i . F_k for every dof i on the path root..k (ancestor bitmask; loads independent)
+    for (unsigned mk = dofanc; mk; mk &= mk - 1) {
+      const int a = __ffs(mk) - 1;
+      const int i0 = a == 0 ? 0 : 5 + a, i1 = a == 0 ? 5 : 5 + a;
+      for (int i = i0; i <= i1; i++) {
+        if (i > k) continue;
+        T val = 0;
 #pragma unroll
-          for (int e = 0; e < 6; e++) val += K.S[i][e] * Fk[e];
-          L.Dyn[i * LDD + k] = val;
-          L.Dyn[k * LDD + i] = val;
-        }
-        break;
+        for (int e = 0; e < 6; e++) val += K.S[i][e] * Fk[e];
+        L.Dyn[i * LDD + k] = val;
+        L.Dyn[k * LDD + i] = val;
       }
-      const int i = 5 + a;
-      T val = 0;
-#pragma unroll
-      for (int e = 0; e < 6; e++) val += K.S[i][e] * Fk[e];
-      L.Dyn[i * LDD + k] = val;
-      L.Dyn[k * LDD + i] = val;
-      a = m.pin_parent[a];
     }
   }
   // ---- frames (lanes 0,1): placement, velocity, classical drift acceleration (LOCAL)

@@ -227,6 +227,26 @@ def convex_hull_graph(verts):
     return verts[ids], adr, np.array(edges, np.int32)
 
 
+CHUNK = 64  # hull vertices per spatial chunk (= one wavefront-wide load)
+
+
+def kd_order(pts, leaf=CHUNK):
+    """Permutation that groups points into spatially compact runs of `leaf` (recursive median split on
+    the widest axis, left part sized to a multiple of `leaf`), so that each run has a tight box."""
+    idx = np.arange(len(pts))
+
+    def rec(ids):
+        if len(ids) <= leaf:
+            return [ids]
+        ext = pts[ids].max(0) - pts[ids].min(0)
+        ax = int(np.argmax(ext))
+        order = ids[np.argsort(pts[ids, ax], kind="stable")]
+        half = ((len(ids) // 2 + leaf - 1) // leaf) * leaf
+        return rec(order[:half]) + rec(order[half:])
+
+    return np.concatenate(rec(idx))
+
+
 def build_sim_model(mjcf_robot: Path, mesh_dir: Path):
     root = ET.parse(mjcf_robot).getroot()
     dflt = root.find("default").find("default")
@@ -271,12 +291,27 @@ def build_sim_model(mjcf_robot: Path, mesh_dir: Path):
     actuators = [p.get("joint") for p in root.find("actuator").findall("position")]
 
     hull_v, hull_adr, edge_adr, edges, rb = [], [0], [0], [], []
+    chunk_adr, chunk_box = [0], []
     for b in bodies:
         v = load_stl_vertices(mesh_dir / mesh_file[b["mesh"]])
         hv, eadr, e = convex_hull_graph(v)
         Rg = quat_wxyz_to_R(b["gquat"])
         hv_body = hv @ Rg.T + b["gpos"]  # the XML geom frame is the STL frame (MuJoCo's own
         # re-centering of the mesh moves geom_pos/quat and the vertices by inverse amounts)
+        # spatial order: runs of CHUNK vertices with a bounding box each (exact pruning of the support search)
+        perm = kd_order(hv_body)
+        inv = np.empty_like(perm)
+        inv[perm] = np.arange(len(perm))
+        hv_body = hv_body[perm]
+        nb_lists = [sorted(int(inv[j]) for j in e[eadr[old]:eadr[old + 1]]) for old in perm]
+        eadr = np.concatenate([[0], np.cumsum([len(x) for x in nb_lists])]).astype(np.int32)
+        e = np.array([j for x in nb_lists for j in x], np.int32)
+        for c0 in range(0, len(hv_body), CHUNK):
+            blk = hv_body[c0:c0 + CHUNK]
+            lo, hi = blk.min(0), blk.max(0)
+            chunk_box.append(np.concatenate([0.5 * (lo + hi), 0.5 * (hi - lo)]))
+        chunk_adr.append(len(chunk_box))
+        assert chunk_adr[-1] - chunk_adr[-2] <= 64, "a hull may have at most 64 chunks (4096 vertices)"
         c = 0.5 * (hv_body.min(0) + hv_body.max(0))
         rb.append(np.concatenate([c, [np.linalg.norm(hv_body - c, axis=1).max()]]))
         hull_v.append(hv_body)
@@ -288,6 +323,7 @@ def build_sim_model(mjcf_robot: Path, mesh_dir: Path):
         frictionloss=frictionloss, armature=armature, kp=kp, dampratio=dampratio,
         hull_v=np.concatenate(hull_v), hull_adr=np.array(hull_adr, np.int32),
         edge_adr=np.array(edge_adr, np.int32), edges=np.array(edges, np.int32), rbound=np.array(rb),
+        chunk_adr=np.array(chunk_adr, np.int32), chunk_box=np.array(chunk_box),
     )
 
 
@@ -419,6 +455,7 @@ def compile_model(ref_root: Path, out: Path):
         "mj_hull_adr": sim["hull_adr"], "mj_hull_vert": sim["hull_v"],
         "mj_hull_eadr": sim["edge_adr"], "mj_hull_edge": sim["edges"],
         "mj_rbound": sim["rbound"], "mj_pairs": np.array(pairs, np.int32),
+        "mj_chunk_adr": sim["chunk_adr"], "mj_chunk_box": sim["chunk_box"],
         # MuJoCo option / contact defaults (no <option>, no geom contact attrs in the MJCF)
         "mj_opt": np.array([0.002, -9.81, 1e-8, 100, 50, 0.01, 1.0]),  # dt gz tol iters ls_iters ls_tol impratio
         "mj_contact": np.array([1.0, 0.02, 1.0, 0.9, 0.95, 0.001, 0.5, 2.0]),  # mu, solref[2], solimp[5]
