@@ -127,9 +127,7 @@ def main():
     def one_step(i, timed_idx=None):
         if sched is not None:
             t = i * conf.dt
-            sLF, sRF, cLF, cRF = sched.sample(t)
-            wc.update_tasks(sLF, sRF, cLF, cRF)
-            wc.com_ref[:, :2] = sched.com_xy(t)
+            sched.apply(wc, t)
         if timed_idx is None:
             wc.tick()
             wc.sim_step()

@@ -82,6 +82,18 @@ int tsidb_step(tsidb_handle h, void *q, void *v, void *qpos, void *qvel, void *q
                void *f, int32_t *status, void *obs, void *frames, int32_t *ncon, int32_t *con_pairs,
                int32_t *info, int n_substeps, void *stream);
 
+/* walking reference update for every env, on the device (config 3): what the reference's main.py:117
+ * intends with controller.update_tasks(sampleLF, sampleRF, contact_LF, contact_RF) when the samples
+ * come from ctrl/Walk_Planner.py:23-31 swing trajectories (ctrl/Foot_Trajectory.py polynomials) over
+ * a ctrl/Footstep_Planner.py plan.  coef [N,K,4,4] = x, y, z, yaw cubic coefficients (ascending, in
+ * time since the step started); side [N,K] int32 = swinging foot of step k (0 left); nsteps [N] int32;
+ * rest [N,K+1,2,3] = (x, y, yaw) of [left, right] foot before step k.  Writes the registered
+ * foot_ref / contact_ref / contact_active / com_ref[:, 0:2] buffers; contact on/off edges re-reference
+ * at `frames` [N,2,12] (current sole placements from the last tsidb_tick), as
+ * ctrl/WalkController.py:215-253 intends. */
+int tsidb_walk_update(tsidb_handle h, const void *coef, const int32_t *side, const int32_t *nsteps,
+                      const void *rest, int K, double t, double step_duration, const void *frames, void *stream);
+
 /* probe of formulation.computeProblemData's rigid-body terms (main.py:119): M [N,26,26],
  * hbias [N,26], Jcom [N,3,26], Jf [N,2,6,26] (LOCAL), oMf [N,2,12], com [N,3].  Test/debug use. */
 int tsidb_rbd_terms(tsidb_handle h, const void *q, const void *v, void *M, void *hbias, void *Jcom, void *Jf,

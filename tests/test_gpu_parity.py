@@ -180,6 +180,28 @@ def test_contact_switching_and_walking_refs_f64(oracle):
     assert seen_single
 
 
+def test_walk_update_kernel_equals_host_path():
+    """tsidb_walk_update (one kernel) == update_tasks(sample(t)) + com_xy (tensor expressions)."""
+    from tsid_control_amd.walk_planner import WalkSchedule
+    n = 40
+    a, b = make(n, sim_enabled=False), make(n, sim_enabled=False)
+    lf, rf = a.frames[0, 0, 9:11].cpu().numpy(), a.frames[0, 1, 9:11].cpu().numpy()
+    sa = WalkSchedule.from_demo_paths(n, a.conf, a.device, a.dtype, seed=3, q0_feet=(lf, rf))
+    sb = WalkSchedule.from_demo_paths(n, b.conf, b.device, b.dtype, seed=3, q0_feet=(lf, rf))
+    for i in range(0, 700, 7):
+        t = i * a.conf.dt
+        sa.apply(a, t)
+        sLF, sRF, cLF, cRF = sb.sample(t)
+        b.update_tasks(sLF, sRF, cLF, cRF)
+        b.com_ref[:, :2] = sb.com_xy(t)
+        assert torch.equal(a.contact_active, b.contact_active), i
+        assert float((a.foot_ref - b.foot_ref).abs().max()) < 1e-12, i
+        assert float((a.contact_ref - b.contact_ref).abs().max()) == 0, i
+        assert float((a.com_ref - b.com_ref).abs().max()) < 1e-12, i
+        a.tick(); b.tick()
+    assert int((a.contact_active.sum(dim=1) == 1).sum()) > 0
+
+
 def test_infeasible_envs_are_flagged_not_fatal(oracle):
     wc = make(6)
     wc.conf.fMin, wc.conf.fMax = 500.0, 400.0

@@ -111,6 +111,67 @@ __global__ __launch_bounds__(WAVE) void k_reset(const DevModel<T> *__restrict__ 
   if (lane < 2) cact[E * 2 + lane] = 1;
 }
 
+// walking reference update: one lane per env (Walk_Planner.py:23-31 samples -> WalkController.py:189-253)
+template <typename T>
+__global__ __launch_bounds__(256) void k_walk(int n, const T *coef, const int *side, const int *nsteps, const T *rest, int K,
+                                              T t, T Tstep, const T *frames, T *foot_ref, T *contact_ref, uint8_t *cact,
+                                              T *com_ref) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  const size_t E = (size_t)e;
+  const int k = (int)floor(t / Tstep);
+  const T s = t - k * Tstep;
+  const int ns = nsteps[e];
+  const bool walking = k < ns;
+  const int kc = k < (ns > 0 ? ns - 1 : 0) ? k : (ns > 0 ? ns - 1 : 0);
+  const int sd = side[E * K + kc];
+  const int kr = k < ns ? k : ns;
+  const T *c = coef + (E * K + kc) * 16;
+  const T pw[4] = {T(1), s, s * s, s * s * s}, d1[4] = {T(0), T(1), 2 * s, 3 * s * s}, d2[4] = {T(0), T(0), T(2), 6 * s};
+  T pos[4], vel[4], acc[4];
+#pragma unroll
+  for (int a = 0; a < 4; a++) {
+    pos[a] = vel[a] = acc[a] = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) { pos[a] += c[4 * a + i] * pw[i]; vel[a] += c[4 * a + i] * d1[i]; acc[a] += c[4 * a + i] * d2[i]; }
+  }
+#pragma unroll
+  for (int f = 0; f < 2; f++) {
+    const bool swing = walking && sd == f;
+    const T *rs = rest + ((E * (K + 1) + kr) * 2 + f) * 3;
+    const T x = swing ? pos[0] : rs[0], y = swing ? pos[1] : rs[1], z = swing ? pos[2] : T(0), yaw = swing ? pos[3] : rs[2];
+    const T cy = cos(yaw), sy = sin(yaw);
+    T smp[24] = {x, y, z, cy, sy, 0, -sy, cy, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (swing) {
+      smp[12] = vel[0]; smp[13] = vel[1]; smp[14] = vel[2]; smp[17] = vel[3];
+      smp[18] = acc[0]; smp[19] = acc[1]; smp[20] = acc[2]; smp[23] = acc[3];
+    }
+    const bool active = cact[E * 2 + f] != 0;
+    const T *fr = frames + E * 24 + 12 * f; // R row-major, p
+    T cur[12] = {fr[9], fr[10], fr[11], fr[0], fr[3], fr[6], fr[1], fr[4], fr[7], fr[2], fr[5], fr[8]};
+    T *fo = foot_ref + E * 48 + 24 * f;
+    if (!swing && !active) { // add_contact: re-reference the contact at the current placement
+#pragma unroll
+      for (int i = 0; i < 12; i++) contact_ref[E * 24 + 12 * f + i] = cur[i];
+      cact[E * 2 + f] = 1;
+    }
+    if (swing && active) { // remove_contact: the foot task restarts from the current placement
+#pragma unroll
+      for (int i = 0; i < 24; i++) fo[i] = i < 12 ? cur[i] : T(0);
+      cact[E * 2 + f] = 0;
+    } else {
+#pragma unroll
+      for (int i = 0; i < 24; i++) fo[i] = smp[i];
+    }
+  }
+  // planar CoM target: midpoint of the feet, blended linearly over the step
+  const int k0 = kr, k1 = k0 + 1 < ns ? k0 + 1 : ns;
+  const T *r0 = rest + (E * (K + 1) + k0) * 6, *r1 = rest + (E * (K + 1) + k1) * 6;
+  const T a = s / Tstep;
+  com_ref[E * 9 + 0] = (1 - a) * T(0.5) * (r0[0] + r0[3]) + a * T(0.5) * (r1[0] + r1[3]);
+  com_ref[E * 9 + 1] = (1 - a) * T(0.5) * (r0[1] + r0[4]) + a * T(0.5) * (r1[1] + r1[4]);
+}
+
 // ============================================================================ host side
 namespace {
 
@@ -502,6 +563,25 @@ int tsidb_step(tsidb_handle h, void *q, void *v, void *qpos, void *qvel, void *q
       if (sim) launch_sim<float>(h, q, qpos, qvel, qacc_ws, nullptr, ncon, con_pairs, info, s);
     }
   }
+  GUARD_END
+}
+
+int tsidb_walk_update(tsidb_handle h, const void *coef, const int32_t *side, const int32_t *nsteps, const void *rest, int K,
+                      double t, double step_duration, const void *frames, void *stream) {
+  GUARD_BEGIN
+  need_refs(h);
+  if (!coef || !side || !nsteps || !rest || !frames || K <= 0) throw std::string("tsidb_walk_update: null table or K <= 0");
+  hipStream_t s = (hipStream_t)stream;
+  const int grid = (h->num_envs + 255) / 256;
+  if (h->dtype == TSIDB_F64)
+    hipLaunchKernelGGL(k_walk<double>, dim3(grid), dim3(256), 0, s, h->num_envs, (const double *)coef, side, nsteps,
+                       (const double *)rest, K, t, step_duration, (const double *)frames, (double *)h->foot_ref,
+                       (double *)h->contact_ref, (uint8_t *)h->contact_active, (double *)h->com_ref);
+  else
+    hipLaunchKernelGGL(k_walk<float>, dim3(grid), dim3(256), 0, s, h->num_envs, (const float *)coef, side, nsteps,
+                       (const float *)rest, K, (float)t, (float)step_duration, (const float *)frames, (float *)h->foot_ref,
+                       (float *)h->contact_ref, (uint8_t *)h->contact_active, (float *)h->com_ref);
+  HIP_OK(hipGetLastError());
   GUARD_END
 }
 

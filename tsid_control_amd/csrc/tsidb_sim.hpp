@@ -22,13 +22,18 @@ constexpr int LDM = 27;
 template <typename T>
 struct SimLds {
   T R[NB][9], p[NB][3];
-  T S[NV][6], V[NB][6], A[NB][6], f[NB][6];
-  T Y[NB][10], Yc[NB][10];
-  T K[NB][21];      // per-body contact inertia (packed sym 6x6), composite after the gather
-  T Wc[MAXCON][21]; // per-contact sum_rows D w w^T
-  T M[NV * LDM], H[NV * LDM];
+  T S[NV][6];
+  union { // tree-pass scratch is dead once bias forces and M exist; the Newton loop reuses the space
+    struct { T V[NB][6], A[NB][6], f[NB][6], Yc[NB][10]; };
+    struct { T K[NB][21]; }; // per-body contact inertia (packed sym 6x6), composite over subtrees
+  };
+  T M[NV * LDM];
+  union { // per-contact inertias are folded into K before the Hessian is assembled
+    T H[NV * LDM];
+    T Wc[MAXCON][21];
+  };
   T qpos[NQ], qvel[NV], ctrl[NA];
-  T qfs[NV], qas[NV], qacc[NV], bias[NV], xv[NV], yv[NV];
+  T qfs[NV], qas[NV], bias[NV], xv[NV];
   int cbody[MAXCON], cvert[MAXCON];
   unsigned anc[NB]; // ancestor bitmask per body (copied from the model: LDS latency, not global)
   T cr[MAXCON][3], cdist[MAXCON], cfv[MAXCON][3]; // contact point (rel O), distance, force vector
@@ -163,7 +168,6 @@ __device__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L, int lane, const
   if (lane < NV) L.qvel[lane] = qvel_g[lane];
   if (lane < NA) L.ctrl[lane] = q_tsid ? q_tsid[m.mj_ctrl_qidx[lane]] : T(0);
   for (int i = lane; i < NV * LDM; i += WAVE) L.M[i] = 0;
-  for (int i = lane; i < NB * 21; i += WAVE) (&L.K[0][0])[i] = 0;
   __syncthreads();
   const T Oz = L.qpos[2];
 
@@ -272,7 +276,7 @@ __device__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L, int lane, const
 #pragma unroll
     for (int i = 0; i < 6; i++) L.f[b][i] = Ya[i] + vx[i];
 #pragma unroll
-    for (int i = 0; i < 10; i++) { L.Y[b][i] = Y[i]; L.Yc[b][i] = Y[i]; }
+    for (int i = 0; i < 10; i++) L.Yc[b][i] = Y[i];
   }
   __syncthreads();
   for (int dpt = m.mj_maxdepth - 1; dpt >= 0; dpt--) {

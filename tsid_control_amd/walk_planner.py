@@ -124,6 +124,22 @@ class WalkSchedule:
             out.append((torch.cat([torch.stack([x, y, z], dim=-1), Rcm, v6, a6], dim=-1), ~swing))
         return out[0][0], out[1][0], out[0][1], out[1][1]
 
+    def apply(self, wc, t: float):
+        """Device path of one tick's reference update: foot samples, contact switching and the planar
+        CoM target for every env in one kernel (tsidb_walk_update); equivalent to
+        wc.update_tasks(*self.sample(t)) followed by wc.com_ref[:, :2] = self.com_xy(t)."""
+        import ctypes as C
+        from . import _lib
+        if not hasattr(self, "_side32"):
+            self._side32 = self.side.to(torch.int32).contiguous()
+            self._nsteps32 = self.nsteps.to(torch.int32).contiguous()
+            self._coef_c, self._rest_c = self.coef.contiguous(), self.rest.contiguous()
+        p = lambda x: C.c_void_p(x.data_ptr())
+        with torch.cuda.device(wc.device):
+            rc = wc._L.tsidb_walk_update(wc._h, p(self._coef_c), p(self._side32), p(self._nsteps32), p(self._rest_c), self.K,
+                                         float(t), float(self.conf.step_duration), p(wc.frames), wc._stream())
+        _lib.check(wc._L, wc._h, rc, "tsidb_walk_update")
+
     def com_xy(self, t: float):
         """Planar CoM target: midpoint of the two foot targets, blended linearly over the step."""
         T = self.conf.step_duration
