@@ -160,6 +160,12 @@ def main():
     alg_bytes = n * dom_words * wsz
     achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
     n_bad = int((wc.status != 0).sum().item())
+    qp_it = wc.info[:, 0].float()
+    stats = {"qp_iters_mean": float(qp_it.mean()), "qp_iters_max": int(qp_it.max()),
+             "frac_envs_in_active_set_loop": float((qp_it > 1).float().mean()),
+             "active_rows_mean": float(wc.info[:, 1].float().mean()), "ncon_mean": float(wc.ncon.float().mean()),
+             "newton_iters_mean": float(wc.info[:, 2].float().mean()),
+             "single_support_frac": float((wc.contact_active.sum(dim=1) == 1).float().mean())}
 
     if rank == 0:
         value = world * n * args.steps / el
@@ -171,7 +177,7 @@ def main():
                                     "update_tasks each tick; TSID tick + sim step)" if args.workload == "walk" else
                                     "cfg2: perturbed stand/balance per GPU"),
                        "envs_per_gpu": n, "global_envs": n * world, "parallelism": f"env-sharded x{world}, obs all-gather",
-                       "qp_failed_envs_last_step": n_bad},
+                       "qp_failed_envs_last_step": n_bad, "last_step_stats": stats},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": dom_ms,

@@ -13,9 +13,16 @@ N = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 conf = RobotConfig(); conf.dtype = dtype
 wc = WalkController(conf, num_envs=N)
 torch.manual_seed(0)
-wc.q[:, 7:] += (torch.rand(N, 20, dtype=wc.dtype, device=wc.device) - 0.5) * 0.1
-wc.v[:] = torch.randn(N, 26, dtype=wc.dtype, device=wc.device) * 0.05
-for _ in range(5): wc.step()
+if len(sys.argv) > 3 and sys.argv[3] == "walk":
+    from tsid_control_amd.walk_planner import WalkSchedule
+    lf, rf = wc.frames[0, 0, 9:11].cpu().numpy(), wc.frames[0, 1, 9:11].cpu().numpy()
+    sched = WalkSchedule.from_demo_paths(N, conf, wc.device, wc.dtype, seed=1, q0_feet=(lf, rf))
+    for i in range(int(sys.argv[4]) if len(sys.argv) > 4 else 100):
+        sched.apply(wc, i * conf.dt); wc.step()
+else:
+    wc.q[:, 7:] += (torch.rand(N, 20, dtype=wc.dtype, device=wc.device) - 0.5) * 0.1
+    wc.v[:] = torch.randn(N, 26, dtype=wc.dtype, device=wc.device) * 0.05
+    for _ in range(5): wc.step()
 torch.cuda.synchronize()
 L = _lib.load()
 n = min(N, 8192)

@@ -17,33 +17,43 @@
 
 namespace tsidb {
 
+constexpr int SLOT0 = 12; // J columns below 12 always belong to equality constraints
+constexpr int NAS = 34;   // room for the active inequalities (at most n - p = 32)
+
 template <typename T>
-struct KinScratch { // aliased onto the J factor's LDS; dead before the QP starts
+struct KinScratch { // rigid-body passes; dead before the QP starts
   T R[NJ][9], p[NJ][3], S[NV][6], V[NJ][6], A[NJ][6], f[NJ][6], Yc[NJ][10], F[NV][6];
   T fR[2][9], fp[2][3];
 };
 
 template <typename T>
+struct ActiveSetLds { // dual active-set bookkeeping; J itself lives in registers
+  T Ra[NAS * (NAS + 1) / 2 + 2]; // packed upper-triangular factor of the active inequality normals
+  T Rinv[NAS + 2];               // reciprocal diagonal
+  T s[160];
+  int slot[NAS + 2], A[NAS + 2], Aold[NAS + 2];
+  unsigned char cstate[160];     // bit0: in the active set, bit1: excluded for this outer iteration
+};
+
+template <typename T>
 struct TickLds {
   union {
-    T J[NVAR * LDJ];
     KinScratch<T> k;
+    ActiveSetLds<T> as;
   };
-  T R[NVAR * (NVAR + 1) / 2 + 1];
   T Dyn[NV * LDD]; // row r = [M[r][0:26] | -Jc[:, r]^T]  (rows 0..5: base dynamics, 6..25: actuation)
   T Jf[12 * LDF];  // frame Jacobians, LOCAL (LF rows 0..5, RF rows 6..11)
   T Jcom[3 * LDF];
   T h[NV];
-  T x[NVAR], g[NVAR], d[NVAR], z[NVAR], r[NVAR + 2], np[NVAR], u[NVAR + 2], xold[NVAR], uold[NVAR + 2];
-  T s[160];
+  T x[NVAR];
+  T fstage[24];
   T arhs[4][6]; // a_des - drift: contact LF, contact RF, foot LF, foot RF
   T acomr[3], apost[NA];
   T oMf[2][12]; // frame placement: R row-major, p (world)
   T vf[2][6], af[2][6];
   T com[3], vcom[3], acomd[3];
   T qs[NQ], vs[NV];
-  int A[NVAR + 2], Aold[NVAR + 2];
-  unsigned char cstate[160]; // bit0: in the active set, bit1: excluded for this outer iteration
+  T vstage[NV];
 };
 
 template <typename T> __device__ __forceinline__ T bcast(T v, int src) { return __shfl(v, src, WAVE); }
@@ -371,155 +381,43 @@ __device__ T row_value(const DevModel<T> &m, const TickLds<T> &L, const QpCtx<T>
   return up ? hi - L.x[k] : L.x[k] - lo;
 }
 
-// materialise the normal of inequality row r into L.np and return its nonzero range
-template <typename T>
-__device__ void row_fill(const DevModel<T> &m, TickLds<T> &L, const QpCtx<T> &c, int r, int lane, int &i0, int &i1) {
-  const int nc = 34 * c.nslot;
-  T val = 0;
-  if (r < nc) {
-    const int s = r / 34, rr = r % 34, up = rr >= 17, b = rr % 17;
-    i0 = NV + 12 * s; i1 = i0 + 12;
-    if (lane >= i0 && lane < i1) val = up ? -m.Bcone[b][lane - i0] : m.Bcone[b][lane - i0];
-  } else if (r < nc + 2 * NA) {
-    const int a = r - nc, up = a >= NA, j = a % NA;
-    i0 = 0; i1 = c.n;
-    if (lane < c.n) val = up ? -L.Dyn[(6 + j) * LDD + lane] : L.Dyn[(6 + j) * LDD + lane];
-  } else {
-    const int b = r - nc - 2 * NA, up = b >= NV, k = b % NV;
-    i0 = k; i1 = k + 1;
-    if (lane == k) val = up ? T(-1) : T(1);
-  }
-  if (lane < c.n) L.np[lane] = val;
-  __syncthreads();
+// v_readlane with a wave-uniform but run-time lane index
+__device__ __forceinline__ float rdlane_dyn(float v, int src) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), __builtin_amdgcn_readfirstlane(src)));
+}
+__device__ __forceinline__ double rdlane_dyn(double v, int src) {
+  const int sl = __builtin_amdgcn_readfirstlane(src);
+  const long long b = __builtin_bit_cast(long long, v);
+  const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffLL), sl), hi = __builtin_amdgcn_readlane((int)(b >> 32), sl);
+  return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+// jr[cidx] for a wave-uniform run-time column index (registers cannot be indexed dynamically)
+template <typename T> __device__ __forceinline__ T col_select(const T (&jr)[NVAR], int cidx) {
+  T r = 0;
+#pragma unroll
+  for (int j = SLOT0; j < NVAR; j++) r = (j == cidx) ? jr[j] : r;
+  return r;
 }
 
-// d = J^T np ; Householder the tail d[iq:] onto d[iq] (rotating J's free columns) ; z = J[:,iq] d[iq] ;
-// r = R^-1 d[:iq].  Returns z.z and z.np.
+// Goldfarb-Idnani dual active set (eiquadprog-fast's control flow and tie-breaking) with the factor
+// J = L^-T Q held in REGISTERS: lane i owns row i (jr[0..49]).  Columns keep fixed register slots; a
+// 64-bit mask marks the free ones (initially p..n-1) and slot[k] names the column that carries the
+// k-th active inequality, so that no register is ever indexed by a run-time value.  A constraint add
+// is one Householder reflection of the free columns onto the lowest free slot.  Cross-lane pieces use
+// v_readlane (sparse normals) or DPP wave sums (dense normals).  Only the small triangular factor of
+// the active inequality normals, the row values and flags live in LDS.  The multipliers of the
+// equality constraints are not tracked (nothing downstream reads them).
 template <typename T>
-__device__ void step_direction(TickLds<T> &L, QpCtx<T> &c, int lane, int i0, int i1, T &zz, T &znp) {
-  const int n = c.n, iq = c.iq;
-  if (lane < n) {
-    T acc = 0;
-    for (int i = i0; i < i1; i++) acc += L.J[i * LDJ + lane] * L.np[i];
-    L.d[lane] = acc;
-  }
-  __syncthreads();
-  zz = 0; znp = 0;
-  if (iq < n) {
-    T dj = (lane > iq && lane < n) ? L.d[lane] : T(0);
-    T sigma = wave_sum(dj * dj);
-    T alpha = L.d[iq];
-    if (sigma > 0) {
-      T nrm = sqrt(alpha * alpha + sigma);
-      T v0 = alpha + (alpha >= 0 ? nrm : -nrm);
-      T beta = T(2) / (v0 * v0 + sigma);
-      if (lane == iq) L.z[iq] = v0;
-      else if (lane > iq && lane < n) L.z[lane] = dj;
-      __syncthreads();
-      if (lane < n) {
-        T w = 0;
-        for (int j = iq; j < n; j++) w += L.J[lane * LDJ + j] * L.z[j];
-        w *= beta;
-        for (int j = iq; j < n; j++) L.J[lane * LDJ + j] -= w * L.z[j];
-      }
-      if (lane == iq) L.d[iq] = alpha >= 0 ? -nrm : nrm;
-      else if (lane > iq && lane < n) L.d[lane] = 0;
-      __syncthreads();
-    }
-    const T diq = L.d[iq];
-    T zi = 0;
-    if (lane < n) { zi = L.J[lane * LDJ + iq] * diq; }
-    zz = wave_sum(zi * zi);
-    znp = diq * diq;
-    __syncthreads();
-    if (lane < n) L.z[lane] = zi;
-  } else {
-    if (lane < n) L.z[lane] = 0;
-  }
-  // r = R^-1 d[:iq], column-oriented back substitution on packed R
-  T rl = lane < iq ? L.d[lane] : T(0);
-  for (int j = iq - 1; j >= 0; j--) {
-    const T rj = bcast(rl, j) / L.R[rcol(j) + j];
-    if (lane == j) rl = rj;
-    else if (lane < j) rl -= L.R[rcol(j) + lane] * rj;
-  }
-  if (lane < iq) L.r[lane] = rl;
-  __syncthreads();
-}
-
-// append the current direction as active constraint column iq; false if numerically dependent
-template <typename T>
-__device__ bool add_constraint(TickLds<T> &L, QpCtx<T> &c, int lane) {
-  const int iq = c.iq;
-  if (iq >= c.n) return false;
-  if (lane <= iq) L.R[rcol(iq) + lane] = L.d[lane];
-  const T dd = fabs(L.d[iq]);
-  c.iq = iq + 1;
-  __syncthreads();
-  if (dd <= Eps<T>::v * c.R_norm) return false;
-  if (dd > c.R_norm) c.R_norm = dd;
-  return true;
-}
-
-// remove active constraint l (an inequality index) from the working set
-template <typename T>
-__device__ void delete_constraint(TickLds<T> &L, QpCtx<T> &c, int lane, int l) {
-  const int n = c.n;
-  int iq = c.iq;
-  int cand = (lane >= c.p && lane < iq && L.A[lane] == l) ? lane : 9999;
-  const int qq = wave_min_int(cand);
-  if (qq >= iq) return;
-  // Givens sweep: old column j+1 becomes column j, rotations act on rows (j, j+1)
-  for (int j = qq; j < iq - 1; j++) {
-    const int co = j + 1;
-    T cc = L.R[rcol(co) + j], ss = L.R[rcol(co) + j + 1];
-    T h = hypot(cc, ss);
-    if (h == 0) continue;
-    cc /= h; ss /= h;
-    T diag = h;
-    if (cc < 0) { cc = -cc; ss = -ss; diag = -h; }
-    const T xny = ss / (T(1) + cc);
-    __syncthreads();
-    for (int k = co + 1 + lane; k < iq; k += WAVE) {
-      T t1 = L.R[rcol(k) + j], t2 = L.R[rcol(k) + j + 1];
-      T n1 = t1 * cc + t2 * ss;
-      L.R[rcol(k) + j] = n1;
-      L.R[rcol(k) + j + 1] = xny * (t1 + n1) - t2;
-    }
-    if (lane == 0) { L.R[rcol(co) + j] = diag; L.R[rcol(co) + j + 1] = 0; }
-    if (lane < n) {
-      T t1 = L.J[lane * LDJ + j], t2 = L.J[lane * LDJ + j + 1];
-      T n1 = t1 * cc + t2 * ss;
-      L.J[lane * LDJ + j] = n1;
-      L.J[lane * LDJ + j + 1] = xny * (n1 + t1) - t2;
-    }
-    __syncthreads();
-  }
-  // shift packed columns left (sequential over columns, lanes over rows)
-  for (int k = qq + 1; k < iq; k++) {
-    T val = lane < k ? L.R[rcol(k) + lane] : T(0);
-    __syncthreads();
-    if (lane < k) L.R[rcol(k - 1) + lane] = val;
-    __syncthreads();
-  }
-  // shift A and u (slot iq holds the candidate and moves down too)
-  int Av = 0;
-  T uv = 0;
-  if (lane >= qq && lane < iq) { Av = L.A[lane + 1]; uv = L.u[lane + 1]; }
-  __syncthreads();
-  if (lane >= qq && lane < iq) { L.A[lane] = Av; L.u[lane] = uv; }
-  if (lane == 0) { L.A[iq] = 0; L.u[iq] = 0; }
-  c.iq = iq - 1;
-  __syncthreads();
-}
-
-// Goldfarb-Idnani dual active set over the LDS-resident problem.  On entry L.J = L^-T, L.x = -H^-1 g.
-template <typename T>
-__device__ int qp_solve(const DevModel<T> &m, TickLds<T> &L, QpCtx<T> &c, int lane, T c1, T c2, int max_iter, int &iter_out) {
-  const int n = c.n;
+__device__ __forceinline__ int qp_active_regs(const DevModel<T> &m, TickLds<T> &L, QpCtx<T> &c, int lane, T (&jr)[NVAR], T &xl,
+                                              T c1, T c2, int max_iter, int &iter_out) {
+  ActiveSetLds<T> &S = L.as;
+  const int n = c.n, p = c.p;
   const T INF = Eps<T>::inf;
-  // the equality constraints are already in the working set (c.iq == c.p, J, R, x, u, A in LDS)
-  for (int r = lane; r < c.nin; r += WAVE) L.cstate[r] = 0;
+  unsigned long long freem = ((1ull << n) - 1ull) & ~((1ull << p) - 1ull);
+  int na = 0;
+  T ul = 0; // lane k < na: multiplier of the k-th active inequality; lane na: the candidate's
+  T R_norm = c.R_norm;
+  for (int r = lane; r < c.nin; r += WAVE) S.cstate[r] = 0;
   __syncthreads();
 
   int iter = 0, status = -1;
@@ -527,20 +425,20 @@ __device__ int qp_solve(const DevModel<T> &m, TickLds<T> &L, QpCtx<T> &c, int la
     // ---------------- l1: new outer iteration
     iter++;
     if (iter >= max_iter) { status = 3; break; }
+    __syncthreads();
+    if (lane < n) L.x[lane] = xl;
+    __syncthreads();
     T psi = 0;
     for (int r = lane; r < c.nin; r += WAVE) {
-      T sv = row_value(m, L, c, r);
-      L.s[r] = sv;
-      L.cstate[r] &= 1; // clear exclusion marks
+      const T sv = row_value(m, L, c, r);
+      S.s[r] = sv;
+      S.cstate[r] &= 1;
       psi += sv < 0 ? sv : T(0);
     }
     psi = wave_sum(psi);
-    // eiquadprog's feasibility tolerance is stated in float64 epsilons; it is a tolerance on the
-    // constraint values, not a rounding bound, so it does not widen with the arithmetic type
     if (fabs(psi) <= T(c.nin) * T(2.220446049250313e-16) * c1 * c2 * T(100)) { status = 0; break; }
-    if (lane < n) L.xold[lane] = L.x[lane];
-    if (lane < c.iq) { L.uold[lane] = L.u[lane]; L.Aold[lane] = L.A[lane]; }
-    const int iq_old = c.iq;
+    const T xold = xl, uold = ul;
+    if (lane < na) S.Aold[lane] = S.A[lane];
     __syncthreads();
 
     bool outer_done = false;
@@ -549,76 +447,195 @@ __device__ int qp_solve(const DevModel<T> &m, TickLds<T> &L, QpCtx<T> &c, int la
       T best = 0;
       int ip = 0x7fffffff;
       for (int r = lane; r < c.nin; r += WAVE) {
-        T sv = L.s[r];
-        if (L.cstate[r] == 0 && sv < best) { best = sv; ip = r; }
+        const T sv = S.s[r];
+        if (S.cstate[r] == 0 && sv < best) { best = sv; ip = r; }
       }
       wave_argmin(best, ip);
       if (!(best < 0)) { status = 0; break; }
-      int i0, i1;
-      row_fill(m, L, c, ip, lane, i0, i1);
-      if (lane == 0) { L.u[c.iq] = 0; L.A[c.iq] = ip; }
-      __syncthreads();
+      if (lane == na) ul = 0;
+      if (lane == 0) S.A[na] = ip;
+      // structure of the normal of row ip: up to three nonzeros (cone / bound rows) or dense
+      const int nc = 34 * c.nslot;
+      bool sparse = true;
+      int si[3] = {0, 0, 0};
+      T sc[3] = {0, 0, 0};
+      T npl = 0; // dense case: this lane's coefficient
+      if (ip < nc) {
+        const int sl = ip / 34, rr = ip % 34, up = rr >= 17, b = rr % 17, base = NV + 12 * sl;
+        const T sg = up ? T(-1) : T(1);
+        if (b < 16) {
+          const int pt = b >> 2;
+#pragma unroll
+          for (int e = 0; e < 3; e++) { si[e] = base + 3 * pt + e; sc[e] = sg * m.Bcone[b][3 * pt + e]; }
+        } else {
+          sparse = false;
+          if (lane >= base && lane < base + 12) npl = sg * m.Bcone[16][lane - base];
+        }
+      } else if (ip < nc + 2 * NA) {
+        const int a = ip - nc, up = a >= NA, j = a % NA;
+        sparse = false;
+        if (lane < n) npl = (up ? T(-1) : T(1)) * L.Dyn[(6 + j) * LDD + lane];
+      } else {
+        const int b = ip - nc - 2 * NA, up = b >= NV, k = b % NV;
+        si[0] = k; sc[0] = up ? T(-1) : T(1);
+      }
 
       while (true) {
-        // ---------------- l2a: step direction and lengths
-        T zz, znp;
-        step_direction(L, c, lane, i0, i1, zz, znp);
+        // ---------------- l2a: d = J^T np over the column slots (lane j keeps d_j)
+        T dl = 0;
+        if (sparse) {
+#pragma unroll
+          for (int j = SLOT0; j < NVAR; j++) {
+            const T tmp = sc[0] * rdlane_dyn(jr[j], si[0]) + sc[1] * rdlane_dyn(jr[j], si[1]) + sc[2] * rdlane_dyn(jr[j], si[2]);
+            if (lane == j) dl = tmp;
+          }
+        } else {
+#pragma unroll
+          for (int j = SLOT0; j < NVAR; j++) {
+            const T tmp = wave_sum(npl * jr[j]);
+            if (lane == j) dl = tmp;
+          }
+        }
+        // Householder: fold the free columns' part of d onto the lowest free slot
+        const int cstar = freem ? __ffsll((long long)freem) - 1 : -1;
+        T z = 0, zz = 0, znp = 0, dnew = 0;
+        if (cstar >= 0) {
+          const T dfree = ((freem >> lane) & 1ull) ? dl : T(0);
+          const T sigma = wave_sum(lane != cstar ? dfree * dfree : T(0));
+          const T alpha = rdlane_dyn(dl, cstar);
+          dnew = alpha;
+          if (sigma > 0) {
+            const T nrm = sqrt(alpha * alpha + sigma);
+            const T v0 = alpha + (alpha >= 0 ? nrm : -nrm);
+            const T beta = T(2) / (v0 * v0 + sigma);
+            const T vl = lane == cstar ? v0 : dfree;
+            T w = 0;
+#pragma unroll
+            for (int j = SLOT0; j < NVAR; j++) w += jr[j] * rdlane(vl, j);
+            w *= beta;
+#pragma unroll
+            for (int j = SLOT0; j < NVAR; j++) jr[j] -= w * rdlane(vl, j);
+            dnew = alpha >= 0 ? -nrm : nrm;
+          }
+          z = lane < n ? col_select(jr, cstar) * dnew : T(0);
+          zz = wave_sum(z * z);
+          znp = dnew * dnew;
+        }
+        // r = R^-1 d over the active inequalities (lane k <-> k-th active constraint)
+        const int myslot = lane < na ? S.slot[lane] : 0;
+        const T dk = __shfl(dl, myslot, WAVE);
+        T rl = lane < na ? dk : T(0);
+        for (int j = na - 1; j >= 0; j--) {
+          const T rj = bcast(rl, j) * S.Rinv[j];
+          if (lane == j) rl = rj;
+          else if (lane < j) rl -= S.Ra[rcol(j) + lane] * rj;
+        }
+        // ---------------- step lengths
         T t1 = INF;
         int kmin = 0x7fffffff;
-        if (lane >= c.p && lane < c.iq) {
-          T rk = L.r[lane];
-          if (rk > 0) { t1 = L.u[lane] / rk; kmin = lane; }
-        }
+        if (lane < na && rl > 0) { t1 = ul / rl; kmin = lane; }
         wave_argmin(t1, kmin);
-        const int l = kmin < c.iq ? L.A[kmin] : 0;
-        const T sip = L.s[ip];
+        const int l = kmin < na ? S.A[kmin] : 0;
+        const T sip = S.s[ip];
         const T t2 = fabs(zz) > Eps<T>::v ? -sip / znp : INF;
         const T t = t1 < t2 ? t1 : t2;
         if (t >= INF) { status = 1; break; }
+        bool drop = false;
         if (t2 >= INF) { // dual step only
-          if (lane < c.iq) L.u[lane] -= t * L.r[lane];
-          if (lane == 0) L.u[c.iq] += t;
-          if (lane == 0) L.cstate[l] &= ~1;
-          __syncthreads();
-          delete_constraint(L, c, lane, l);
-          continue;
-        }
-        if (lane < n) L.x[lane] += t * L.z[lane];
-        if (lane < c.iq) L.u[lane] -= t * L.r[lane];
-        if (lane == 0) L.u[c.iq] += t;
-        __syncthreads();
-        if (t == t2) { // full step: ip joins the active set
-          if (!add_constraint(L, c, lane)) {
-            if (lane == 0) L.cstate[ip] |= 2;
-            __syncthreads();
-            delete_constraint(L, c, lane, ip);
-            // restore the state saved at l1
-            for (int r = lane; r < c.nin; r += WAVE) L.cstate[r] &= 2;
-            __syncthreads();
-            if (lane < c.iq) {
-              L.A[lane] = L.Aold[lane]; L.u[lane] = L.uold[lane];
-              if (lane >= c.p) L.cstate[L.Aold[lane]] |= 1;
+          if (lane < na) ul -= t * rl;
+          if (lane == na) ul += t;
+          drop = true;
+        } else {
+          xl += t * z;
+          if (lane < na) ul -= t * rl;
+          if (lane == na) ul += t;
+          if (t == t2) { // full step: ip joins the active set on slot cstar
+            const T ad = fabs(dnew);
+            if (na >= NAS - 2 || ad <= Eps<T>::v * R_norm) {
+              // numerically dependent on the active set: exclude it for this outer iteration and
+              // fall back to the state saved at l1 (eiquadprog's recovery path)
+              __syncthreads();
+              if (lane == 0) S.cstate[ip] |= 2;
+              for (int r = lane; r < c.nin; r += WAVE) S.cstate[r] &= 2;
+              __syncthreads();
+              if (lane < na) { S.A[lane] = S.Aold[lane]; S.cstate[S.Aold[lane]] |= 1; }
+              ul = lane < na ? uold : T(0);
+              xl = xold;
+              __syncthreads();
+              break; // back to l2
             }
-            if (lane < n) L.x[lane] = L.xold[lane];
+            if (ad > R_norm) R_norm = ad;
+            if (lane < na) S.Ra[rcol(na) + lane] = dk;
+            if (lane == 0) { S.Ra[rcol(na) + na] = dnew; S.Rinv[na] = T(1) / dnew; S.slot[na] = cstar; S.cstate[ip] |= 1; }
+            freem &= ~(1ull << cstar);
+            na++;
             __syncthreads();
-            (void)iq_old;
-            break; // back to l2
+            outer_done = true;
+            break; // back to l1
           }
-          if (lane == 0) L.cstate[ip] |= 1;
-          __syncthreads();
-          outer_done = true;
-          break; // back to l1
+          drop = true; // partial step
         }
-        // partial step: drop l, refresh s[ip], recompute direction
-        if (lane == 0) L.cstate[l] &= ~1;
-        __syncthreads();
-        delete_constraint(L, c, lane, l);
-        T sv = row_value(m, L, c, ip);
-        if (lane == 0) L.s[ip] = sv;
-        __syncthreads();
+        if (drop) {
+          // ---------------- remove active constraint l, then recompute the direction for ip
+          __syncthreads();
+          if (lane == 0) S.cstate[l] &= ~1;
+          const int qq = wave_min_int((lane < na && S.A[lane] == l) ? lane : 9999);
+          for (int j = qq; j < na - 1; j++) { // Givens sweep restoring the triangular factor
+            const int co = j + 1;
+            T cc = S.Ra[rcol(co) + j], ss = S.Ra[rcol(co) + j + 1];
+            const T h = hypot(cc, ss);
+            if (h == 0) continue;
+            cc /= h; ss /= h;
+            T diag = h;
+            if (cc < 0) { cc = -cc; ss = -ss; diag = -h; }
+            const T xny = ss / (T(1) + cc);
+            __syncthreads();
+            for (int k = co + 1 + lane; k < na; k += WAVE) {
+              const T a1 = S.Ra[rcol(k) + j], a2 = S.Ra[rcol(k) + j + 1];
+              const T n1 = a1 * cc + a2 * ss;
+              S.Ra[rcol(k) + j] = n1;
+              S.Ra[rcol(k) + j + 1] = xny * (a1 + n1) - a2;
+            }
+            if (lane == 0) { S.Ra[rcol(co) + j] = diag; S.Ra[rcol(co) + j + 1] = 0; }
+            const int sa = S.slot[j], sb = S.slot[j + 1];
+            const T ta = col_select(jr, sa), tb = col_select(jr, sb);
+            const T n1 = ta * cc + tb * ss, n2 = xny * (n1 + ta) - tb;
+#pragma unroll
+            for (int jj = SLOT0; jj < NVAR; jj++) jr[jj] = (jj == sa) ? n1 : ((jj == sb) ? n2 : jr[jj]);
+            __syncthreads();
+          }
+          for (int k = qq + 1; k < na; k++) { // shift the packed columns left
+            const T val = lane < k ? S.Ra[rcol(k) + lane] : T(0);
+            __syncthreads();
+            if (lane < k) S.Ra[rcol(k - 1) + lane] = val;
+            __syncthreads();
+          }
+          if (lane >= qq && lane < na - 1) S.Rinv[lane] = T(1) / S.Ra[rcol(lane) + lane];
+          int Av = 0;
+          if (lane >= qq && lane < na) Av = S.A[lane + 1];
+          const T unext = __shfl_down(ul, 1, WAVE);
+          __syncthreads();
+          if (lane >= qq && lane < na) S.A[lane] = Av;
+          if (lane >= qq && lane <= na) ul = unext;
+          const int freed = S.slot[na - 1];
+          freem |= 1ull << freed;
+          na--;
+          if (lane == na + 1) ul = 0;
+          // refresh s[ip] at the new point
+          __syncthreads();
+          if (lane < n) L.x[lane] = xl;
+          __syncthreads();
+          const T sv = row_value(m, L, c, ip);
+          if (lane == 0) S.s[ip] = sv;
+          __syncthreads();
+        }
       }
     }
   }
+  __syncthreads();
+  if (lane < n) L.x[lane] = xl;
+  __syncthreads();
+  c.iq = p + na;
   iter_out = iter;
   return status;
 }
@@ -841,8 +858,8 @@ __device__ void tsid_tick_env(const DevModel<T> &m, TickLds<T> &L, int lane, T *
         if (ad > R_norm) R_norm = ad;
       }
     }
-    // ---- R^T t = -c (forward), u = R^-1 t (backward, uniform), x = x0 + J[:, :p] t
-    T tacc = -ck, tv[18], uv[18];
+    // ---- R^T t = -c (forward), x = x0 + J[:, :p] t  (the equality multipliers u = R^-1 t are not needed)
+    T tacc = -ck, tv[18];
 #pragma unroll
     for (int i = 0; i < 18; i++) {
       tv[i] = 0;
@@ -851,24 +868,13 @@ __device__ void tsid_tick_env(const DevModel<T> &m, TickLds<T> &L, int lane, T *
         tacc -= bc[i] * tv[i];
       }
     }
-#pragma unroll
-    for (int j = 17; j >= 0; j--) {
-      uv[j] = 0;
-      if (j < p) {
-        T ua = tv[j];
-#pragma unroll
-        for (int mm = j + 1; mm < 18; mm++)
-          if (mm < p) ua -= rdlane(bc[j], mm) * uv[mm];
-        uv[j] = ua / rdlane(bc[j], j);
-      }
-    }
     T xeq = lane < NV ? x0 : T(0);
 #pragma unroll
     for (int k = 0; k < 18; k++) xeq += jr[k] * tv[k];
     TSIDB_STAMP(6);
     // ---- first feasibility sweep straight from registers' result; J / R go to LDS only if the
     //      active-set iterations are actually needed
-    if (lane < n) { L.x[lane] = xeq; L.g[lane] = gi; }
+    if (lane < n) L.x[lane] = xeq;
     __syncthreads();
     c.iq = p;
     c.R_norm = R_norm;
@@ -885,26 +891,7 @@ __device__ void tsid_tick_env(const DevModel<T> &m, TickLds<T> &L, int lane, T *
       psi = wave_sum(psi);
       if (fabs(psi) <= T(c.nin) * T(2.220446049250313e-16) * c1 * c2 * T(100)) status = 0;
     }
-    if (status < 0) {
-#pragma unroll
-      for (int j = 0; j < NVAR; j++)
-        if (lane < n) L.J[lane * LDJ + j] = jr[j];
-      if (lane < p) {
-#pragma unroll
-        for (int i = 0; i < 18; i++)
-          if (i <= lane) L.R[rcol(lane) + i] = bc[i];
-      }
-      if (lane < NVAR + 2) {
-        T uu = 0;
-#pragma unroll
-        for (int k = 0; k < 18; k++)
-          if (lane == k) uu = uv[k];
-        L.u[lane] = uu;
-        L.A[lane] = lane < p ? -lane - 1 : 0;
-      }
-      __syncthreads();
-      status = qp_solve(m, L, c, lane, c1, c2, (int)m.params[P_MAX_ITER], iters);
-    }
+    if (status < 0) status = qp_active_regs(m, L, c, lane, jr, xeq, c1, c2, (int)m.params[P_MAX_ITER], iters);
     qp_status = status;
     qp_iters = iters;
   }
@@ -919,7 +906,7 @@ __device__ void tsid_tick_env(const DevModel<T> &m, TickLds<T> &L, int lane, T *
     for (int s = 0; s < c.nslot; s++)
       if (c.slot_foot[s] == fo) val = L.x[NV + 12 * s + e];
     fout[lane] = val;
-    L.s[lane] = val; // staged for the CoP
+    L.fstage[lane] = val; // staged for the CoP
   }
   if (lane < NA) {
     T t = L.h[6 + lane];
@@ -939,7 +926,7 @@ __device__ void tsid_tick_env(const DevModel<T> &m, TickLds<T> &L, int lane, T *
       for (int fo = 0; fo < 2; fo++) {
         T w[6] = {0, 0, 0, 0, 0, 0};
         for (int e = 0; e < 12; e++) {
-          T fe = L.s[12 * fo + e];
+          T fe = L.fstage[12 * fo + e];
 #pragma unroll
           for (int i = 0; i < 6; i++) w[i] += m.Tgen[i][e] * fe;
         }
@@ -971,12 +958,12 @@ __device__ void tsid_tick_env(const DevModel<T> &m, TickLds<T> &L, int lane, T *
       const T vv = L.vs[lane], dd = L.x[lane];
       vm = dt * (vv + T(0.5) * dt * dd);
       L.vs[lane] = vv + dt * dd;
-      L.d[lane] = vm;
+      L.vstage[lane] = vm;
     }
     __syncthreads();
     if (lane >= 6 && lane < NV) L.qs[lane + 1] += vm;
     if (lane == 0) {
-      const T *vl = &L.d[0], *w = &L.d[3];
+      const T *vl = &L.vstage[0], *w = &L.vstage[3];
       const T th2 = dot3(w, w), th = sqrt(th2);
       const T small = sizeof(T) == 8 ? T(1e-8) : T(1e-4);
       T b, cc, sh, ch;
