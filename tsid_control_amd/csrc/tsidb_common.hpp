@@ -132,6 +132,7 @@ template <int CTRL, int ROW_MASK> __device__ __forceinline__ double dpp_mov(doub
 __device__ __forceinline__ float lane63(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
+__device__ __forceinline__ int lane63(int v) { return __builtin_amdgcn_readlane(v, 63); }
 __device__ __forceinline__ double lane63(double v) {
   const long long b = __builtin_bit_cast(long long, v);
   const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffLL), 63), hi = __builtin_amdgcn_readlane((int)(b >> 32), 63);
@@ -168,20 +169,13 @@ template <typename T> __device__ __forceinline__ T wave_min(T v) {
   v = dpp_min_step<0x143, 0xc>(v);
   return lane63(v);
 }
-// (value, index) lexicographic minimum: smallest value, lowest index among equals
+// (value, index) lexicographic minimum: smallest value, lowest index among equals (two DPP reductions)
 template <typename T> __device__ __forceinline__ void wave_argmin(T &v, int &i) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    T w = __shfl_xor(v, o, WAVE);
-    int k = __shfl_xor(i, o, WAVE);
-    if (w < v || (w == v && k < i)) { v = w; i = k; }
-  }
+  const T vmin = wave_min(v);
+  i = wave_min<int>(v == vmin ? i : 0x7fffffff);
+  v = vmin;
 }
-__device__ __forceinline__ int wave_min_int(int v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) { int w = __shfl_xor(v, o, WAVE); v = w < v ? w : v; }
-  return v;
-}
+__device__ __forceinline__ int wave_min_int(int v) { return wave_min<int>(v); }
 
 // quaternion (x,y,z,w order given as separate scalars) -> rotation, normalising
 template <typename T> __device__ __forceinline__ void quat_to_R(T x, T y, T z, T w, T *R) {

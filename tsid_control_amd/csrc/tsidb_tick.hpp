@@ -46,6 +46,7 @@ struct TickLds {
   T Jcom[3 * LDF];
   T h[NV];
   T x[NVAR];
+  T actp[3][NA]; // partial sums of the actuation rows [M_a | -J_a^T] x (three column ranges)
   T fstage[24];
   T arhs[4][6]; // a_des - drift: contact LF, contact RF, foot LF, foot RF
   T acomr[3], apost[NA];
@@ -344,41 +345,95 @@ struct QpCtx {
   T R_norm;
 };
 
-// value of one-sided inequality row r at L.x  (CI x + ci0), rows ordered as tsid stacks them
+// One-sided inequality rows (CI x + ci0 >= 0), ordered as tsid stacks them: per contact slot 17 cone
+// lower + 17 cone upper rows, then 20 + 20 actuation rows, then 26 + 26 acceleration-bound rows.
+// Each lane decodes its (up to three) rows ONCE into registers; a sweep then only touches x.
+//   s = cst + sgn * val ;  kind 0: val = cf . x[idx..idx+2]         (friction pyramid row)
+//                          kind 1: val = sum_pt cf . x[idx+3pt ..]   (normal-force row)
+//                          kind 2: val = [M_a | -J_a^T]_idx . x      (actuation row)
+//                          kind 3: val = x[idx]                      (acceleration bound)
 template <typename T>
-__device__ T row_value(const DevModel<T> &m, const TickLds<T> &L, const QpCtx<T> &c, int r) {
+struct RowDesc {
+  int kind, idx;
+  T sgn, cst, cf[3];
+};
+
+template <typename T>
+__device__ __forceinline__ RowDesc<T> row_desc(const DevModel<T> &m, const TickLds<T> &L, const QpCtx<T> &c, int r) {
+  RowDesc<T> d;
+  d.kind = -1; d.idx = 0; d.sgn = 0; d.cst = 0; d.cf[0] = d.cf[1] = d.cf[2] = 0;
+  if (r >= c.nin) return d;
   const int nc = 34 * c.nslot;
   if (r < nc) {
     const int s = r / 34, rr = r % 34, up = rr >= 17, b = rr % 17;
-    const T *xf = &L.x[NV + 12 * s];
-    T val = 0;
+    d.sgn = up ? T(-1) : T(1);
+    d.cst = up ? m.cone_ub[b] : -m.cone_lb[b];
     if (b < 16) {
-      const int pt = b >> 2;
+      d.kind = 0; d.idx = NV + 12 * s + 3 * (b >> 2);
 #pragma unroll
-      for (int e = 0; e < 3; e++) val += m.Bcone[b][3 * pt + e] * xf[3 * pt + e];
+      for (int e = 0; e < 3; e++) d.cf[e] = m.Bcone[b][3 * (b >> 2) + e];
     } else {
-      for (int e = 0; e < 12; e++) val += m.Bcone[16][e] * xf[e];
+      d.kind = 1; d.idx = NV + 12 * s;
+#pragma unroll
+      for (int e = 0; e < 3; e++) d.cf[e] = m.Bcone[16][e];
     }
-    return up ? m.cone_ub[b] - val : val - m.cone_lb[b];
+    return d;
   }
   r -= nc;
   if (r < 2 * NA) {
     const int up = r >= NA, j = r % NA;
-    T val = 0;
-    for (int e = 0; e < c.n; e++) val += L.Dyn[(6 + j) * LDD + e] * L.x[e];
     const T tm = m.params[P_TAU_MAX + j], hj = L.h[6 + j];
-    return up ? (tm - hj) - val : val - (-tm - hj);
+    d.kind = 2; d.idx = j;
+    d.sgn = up ? T(-1) : T(1);
+    d.cst = up ? tm - hj : tm + hj;
+    return d;
   }
   r -= 2 * NA;
   const int up = r >= NV, k = r % NV;
   T lo = T(-1e10), hi = T(1e10);
   if (k >= 6) {
     const T dt2 = 2 * m.params[P_DT], vmax = m.params[P_V_MAX + k - 6], vk = L.vs[k];
-    T amax = (vmax - vk) / dt2, amin = (-vmax - vk) / dt2;
+    const T amax = (vmax - vk) / dt2, amin = (-vmax - vk) / dt2;
     hi = amax < T(1e10) ? amax : T(1e10);
     lo = amin > T(-1e10) ? amin : T(-1e10);
   }
-  return up ? hi - L.x[k] : L.x[k] - lo;
+  d.kind = 3; d.idx = k;
+  d.sgn = up ? T(-1) : T(1);
+  d.cst = up ? hi : -lo;
+  return d;
+}
+
+// partial sums of the actuation rows at L.x: lane = row + 20 * part, part = one third of the columns
+template <typename T>
+__device__ __forceinline__ void act_partials(TickLds<T> &L, int n, int lane) {
+  if (lane < 3 * NA) {
+    const int j = lane % NA, part = lane / NA, e0 = part * 17, e1 = e0 + 17 < n ? e0 + 17 : n;
+    T a0 = 0, a1 = 0;
+    int e = e0;
+    for (; e + 1 < e1; e += 2) {
+      a0 += L.Dyn[(6 + j) * LDD + e] * L.x[e];
+      a1 += L.Dyn[(6 + j) * LDD + e + 1] * L.x[e + 1];
+    }
+    if (e < e1) a0 += L.Dyn[(6 + j) * LDD + e] * L.x[e];
+    L.actp[part][j] = a0 + a1;
+  }
+}
+
+template <typename T>
+__device__ __forceinline__ T row_eval(const RowDesc<T> &d, const TickLds<T> &L) {
+  T val = 0;
+  if (d.kind == 0) {
+    val = d.cf[0] * L.x[d.idx] + d.cf[1] * L.x[d.idx + 1] + d.cf[2] * L.x[d.idx + 2];
+  } else if (d.kind == 1) {
+#pragma unroll
+    for (int pt = 0; pt < 4; pt++)
+      val += d.cf[0] * L.x[d.idx + 3 * pt] + d.cf[1] * L.x[d.idx + 3 * pt + 1] + d.cf[2] * L.x[d.idx + 3 * pt + 2];
+  } else if (d.kind == 2) {
+    val = L.actp[0][d.idx] + L.actp[1][d.idx] + L.actp[2][d.idx];
+  } else if (d.kind == 3) {
+    val = L.x[d.idx];
+  }
+  return d.cst + d.sgn * val;
 }
 
 // v_readlane with a wave-uniform but run-time lane index
@@ -409,7 +464,7 @@ template <typename T> __device__ __forceinline__ T col_select(const T (&jr)[NVAR
 // equality constraints are not tracked (nothing downstream reads them).
 template <typename T>
 __device__ __forceinline__ int qp_active_regs(const DevModel<T> &m, TickLds<T> &L, QpCtx<T> &c, int lane, T (&jr)[NVAR], T &xl,
-                                              T c1, T c2, int max_iter, int &iter_out) {
+                                              const RowDesc<T> (&rd)[3], T c1, T c2, int max_iter, int &iter_out) {
   ActiveSetLds<T> &S = L.as;
   const int n = c.n, p = c.p;
   const T INF = Eps<T>::inf;
@@ -421,6 +476,8 @@ __device__ __forceinline__ int qp_active_regs(const DevModel<T> &m, TickLds<T> &
   __syncthreads();
 
   int iter = 0, status = -1;
+  TSIDB_LAP_ZERO(10); TSIDB_LAP_ZERO(11); TSIDB_LAP_ZERO(12); TSIDB_LAP_ZERO(13); TSIDB_LAP_ZERO(14);
+  TSIDB_LAP_INIT();
   while (status < 0) {
     // ---------------- l1: new outer iteration
     iter++;
@@ -428,18 +485,25 @@ __device__ __forceinline__ int qp_active_regs(const DevModel<T> &m, TickLds<T> &
     __syncthreads();
     if (lane < n) L.x[lane] = xl;
     __syncthreads();
+    act_partials(L, n, lane);
+    __syncthreads();
     T psi = 0;
-    for (int r = lane; r < c.nin; r += WAVE) {
-      const T sv = row_value(m, L, c, r);
-      S.s[r] = sv;
-      S.cstate[r] &= 1;
-      psi += sv < 0 ? sv : T(0);
+#pragma unroll
+    for (int rr = 0; rr < 3; rr++) {
+      const int r = lane + WAVE * rr;
+      if (r < c.nin) {
+        const T sv = row_eval(rd[rr], L);
+        S.s[r] = sv;
+        S.cstate[r] &= 1;
+        psi += sv < 0 ? sv : T(0);
+      }
     }
     psi = wave_sum(psi);
     if (fabs(psi) <= T(c.nin) * T(2.220446049250313e-16) * c1 * c2 * T(100)) { status = 0; break; }
     const T xold = xl, uold = ul;
     if (lane < na) S.Aold[lane] = S.A[lane];
     __syncthreads();
+    TSIDB_LAP(10);
 
     bool outer_done = false;
     while (!outer_done && status < 0) {
@@ -454,32 +518,39 @@ __device__ __forceinline__ int qp_active_regs(const DevModel<T> &m, TickLds<T> &
       if (!(best < 0)) { status = 0; break; }
       if (lane == na) ul = 0;
       if (lane == 0) S.A[na] = ip;
-      // structure of the normal of row ip: up to three nonzeros (cone / bound rows) or dense
-      const int nc = 34 * c.nslot;
-      bool sparse = true;
+      // structure of the normal of row ip, broadcast from the lane that owns the row's descriptor:
+      // up to three nonzeros (pyramid / bound rows) or dense (normal-force / actuation rows)
+      const int owner = ip & (WAVE - 1), oround = ip >> 6;
+      int okind = 0, oidx = 0;
+      T osgn = 0, ocf[3] = {0, 0, 0};
+#pragma unroll
+      for (int rr = 0; rr < 3; rr++)
+        if (rr == oround) {
+          okind = __builtin_amdgcn_readlane(rd[rr].kind, __builtin_amdgcn_readfirstlane(owner));
+          oidx = __builtin_amdgcn_readlane(rd[rr].idx, __builtin_amdgcn_readfirstlane(owner));
+          osgn = rdlane_dyn(rd[rr].sgn, owner);
+#pragma unroll
+          for (int e = 0; e < 3; e++) ocf[e] = rdlane_dyn(rd[rr].cf[e], owner);
+        }
+      const bool sparse = okind == 0 || okind == 3;
       int si[3] = {0, 0, 0};
       T sc[3] = {0, 0, 0};
       T npl = 0; // dense case: this lane's coefficient
-      if (ip < nc) {
-        const int sl = ip / 34, rr = ip % 34, up = rr >= 17, b = rr % 17, base = NV + 12 * sl;
-        const T sg = up ? T(-1) : T(1);
-        if (b < 16) {
-          const int pt = b >> 2;
+      if (okind == 0) {
 #pragma unroll
-          for (int e = 0; e < 3; e++) { si[e] = base + 3 * pt + e; sc[e] = sg * m.Bcone[b][3 * pt + e]; }
-        } else {
-          sparse = false;
-          if (lane >= base && lane < base + 12) npl = sg * m.Bcone[16][lane - base];
+        for (int e = 0; e < 3; e++) { si[e] = oidx + e; sc[e] = osgn * ocf[e]; }
+      } else if (okind == 3) {
+        si[0] = oidx; sc[0] = osgn;
+      } else if (okind == 1) {
+        if (lane >= oidx && lane < oidx + 12) {
+          const int e = (lane - oidx) % 3;
+          npl = osgn * (e == 0 ? ocf[0] : (e == 1 ? ocf[1] : ocf[2]));
         }
-      } else if (ip < nc + 2 * NA) {
-        const int a = ip - nc, up = a >= NA, j = a % NA;
-        sparse = false;
-        if (lane < n) npl = (up ? T(-1) : T(1)) * L.Dyn[(6 + j) * LDD + lane];
       } else {
-        const int b = ip - nc - 2 * NA, up = b >= NV, k = b % NV;
-        si[0] = k; sc[0] = up ? T(-1) : T(1);
+        if (lane < n) npl = osgn * L.Dyn[(6 + oidx) * LDD + lane];
       }
 
+      TSIDB_LAP(11);
       while (true) {
         // ---------------- l2a: d = J^T np over the column slots (lane j keeps d_j)
         T dl = 0;
@@ -496,6 +567,7 @@ __device__ __forceinline__ int qp_active_regs(const DevModel<T> &m, TickLds<T> &
             if (lane == j) dl = tmp;
           }
         }
+        TSIDB_LAP(12);
         // Householder: fold the free columns' part of d onto the lowest free slot
         const int cstar = freem ? __ffsll((long long)freem) - 1 : -1;
         T z = 0, zz = 0, znp = 0, dnew = 0;
@@ -521,6 +593,7 @@ __device__ __forceinline__ int qp_active_regs(const DevModel<T> &m, TickLds<T> &
           zz = wave_sum(z * z);
           znp = dnew * dnew;
         }
+        TSIDB_LAP(13);
         // r = R^-1 d over the active inequalities (lane k <-> k-th active constraint)
         const int myslot = lane < na ? S.slot[lane] : 0;
         const T dk = __shfl(dl, myslot, WAVE);
@@ -570,6 +643,7 @@ __device__ __forceinline__ int qp_active_regs(const DevModel<T> &m, TickLds<T> &
             freem &= ~(1ull << cstar);
             na++;
             __syncthreads();
+            TSIDB_LAP(14);
             outer_done = true;
             break; // back to l1
           }
@@ -625,8 +699,10 @@ __device__ __forceinline__ int qp_active_regs(const DevModel<T> &m, TickLds<T> &
           __syncthreads();
           if (lane < n) L.x[lane] = xl;
           __syncthreads();
-          const T sv = row_value(m, L, c, ip);
-          if (lane == 0) S.s[ip] = sv;
+          if (okind == 2) { act_partials(L, n, lane); __syncthreads(); }
+#pragma unroll
+          for (int rr = 0; rr < 3; rr++)
+            if (rr == oround && lane == owner) S.s[ip] = row_eval(rd[rr], L);
           __syncthreads();
         }
       }
@@ -882,16 +958,23 @@ __device__ void tsid_tick_env(const DevModel<T> &m, TickLds<T> &L, int lane, T *
     int status = -1;
     if (!spd) status = 2;
     else if (degenerate) { status = 4; iters = 0; }
-    else {
+    RowDesc<T> rdesc[3];
+#pragma unroll
+    for (int rr = 0; rr < 3; rr++) rdesc[rr] = row_desc(m, L, c, lane + WAVE * rr);
+    if (status < 0) {
+      act_partials(L, n, lane);
+      __syncthreads();
       T psi = 0;
-      for (int r = lane; r < c.nin; r += WAVE) {
-        const T sv = row_value(m, L, c, r);
-        psi += sv < 0 ? sv : T(0);
-      }
+#pragma unroll
+      for (int rr = 0; rr < 3; rr++)
+        if (lane + WAVE * rr < c.nin) {
+          const T sv = row_eval(rdesc[rr], L);
+          psi += sv < 0 ? sv : T(0);
+        }
       psi = wave_sum(psi);
       if (fabs(psi) <= T(c.nin) * T(2.220446049250313e-16) * c1 * c2 * T(100)) status = 0;
     }
-    if (status < 0) status = qp_active_regs(m, L, c, lane, jr, xeq, c1, c2, (int)m.params[P_MAX_ITER], iters);
+    if (status < 0) status = qp_active_regs(m, L, c, lane, jr, xeq, rdesc, c1, c2, (int)m.params[P_MAX_ITER], iters);
     qp_status = status;
     qp_iters = iters;
   }
