@@ -21,14 +21,15 @@ constexpr int LDM = 27;
 
 template <typename T>
 struct SimLds {
-  T R[NB][9], p[NB][3];
   T S[NV][6];
   union { // tree-pass scratch is dead once bias forces and M exist; the Newton loop reuses the space
     struct { T V[NB][6], A[NB][6], f[NB][6], Yc[NB][10]; };
     struct { T K[NB][21]; }; // per-body contact inertia (packed sym 6x6), composite over subtrees
   };
   T M[NV * LDM];
-  union { // per-contact inertias are folded into K before the Hessian is assembled
+  union { // body frames are needed until the contacts exist; per-contact inertias are folded into K
+          // before the Hessian is assembled
+    struct { T R[NB][9], p[NB][3]; };
     T H[NV * LDM];
     T Wc[MAXCON][21];
   };

@@ -70,8 +70,6 @@ __device__ __forceinline__ double rdlane(double v, int src) {
   return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
 }
 
-__device__ __forceinline__ float rsqrt_t(float x) { return 1.0f / sqrtf(x); }
-__device__ __forceinline__ double rsqrt_t(double x) { return 1.0 / sqrt(x); }
 
 // --------------------------------------------------------------------------- rigid-body terms
 // Inputs L.qs, L.vs.  Outputs: L.Dyn (M part, rest zero), L.h, L.Jf, L.Jcom, L.oMf, L.vf, L.af,
