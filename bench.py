@@ -106,7 +106,9 @@ def main():
     rank, local, world = init_distributed()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    dev = torch.device("cuda", local if world > 1 else 0)
+    # TSIDB_BENCH_ONE_DEVICE=1 (+ TSIDB_DIST_BACKEND=gloo) rehearses the N > 1 plumbing on a 1-GPU box
+    one_dev = os.environ.get("TSIDB_BENCH_ONE_DEVICE") == "1"
+    dev = torch.device("cuda", local if (world > 1 and not one_dev) else 0)
     torch.cuda.set_device(dev)
     n = args.envs_per_gpu
     conf = RobotConfig()
@@ -167,6 +169,11 @@ def main():
              "newton_iters_mean": float(wc.info[:, 2].float().mean()),
              "single_support_frac": float((wc.contact_active.sum(dim=1) == 1).float().mean())}
 
+    traffic = None
+    tf = ROOT / "profiles" / "pmc_traffic.json"
+    if tf.exists() and args.dtype == "f64" and n == 4096:
+        traffic = json.loads(tf.read_text()).get(dom, {}).get("bytes_per_launch")  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+
     if rank == 0:
         value = world * n * args.steps / el
         out = {
@@ -179,7 +186,7 @@ def main():
                        "envs_per_gpu": n, "global_envs": n * world, "parallelism": f"env-sharded x{world}, obs all-gather",
                        "qp_failed_envs_last_step": n_bad, "last_step_stats": stats},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": dom_ms,
                          "k_tick_ms": tick_ms, "k_sim_ms": sim_ms,
                          "valu_frac_nominal": (n * NOMINAL_FLOP_PER_ENV_STEP / ((tick_ms + sim_ms) * 1e-3)) / (VALU_PEAK_TFLOPS[args.dtype] * 1e12)},

@@ -23,7 +23,7 @@ def init_distributed(backend=None):
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        be = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+        be = backend or os.environ.get("TSIDB_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if be == "nccl":
             torch.cuda.set_device(local)
         dist.init_process_group(be, rank=rank, world_size=world)
@@ -49,6 +49,14 @@ class ObsGather:
         if self.world == 1:
             self.out.copy_(obs)
             return None
+        if self.out.is_cuda and dist.get_backend() == "gloo":
+            # rehearsal on a box without RCCL peers: stage through the host
+            wide = torch.empty(self.out.shape, dtype=self.out.dtype)
+            if self.equal:
+                dist.all_gather_into_tensor(wide, obs.cpu().contiguous())
+                self.out.copy_(wide)
+                return None
+            raise NotImplementedError("ragged gloo gather of device tensors")
         if self.equal:
             return dist.all_gather_into_tensor(self.out, obs.contiguous(), async_op=async_op)
         self.stage[:obs.shape[0]].copy_(obs)
