@@ -3,6 +3,7 @@
 #include "tsidb_common.hpp"
 #include "tsidb_sim.hpp"
 #include "tsidb_tick.hpp"
+#include "tsidb_topology.hpp"
 
 #include <cmath>
 #include <cstdio>
@@ -342,6 +343,10 @@ static void build_model(tsidb_ctx *h, DevModel<T> &m) {
   }
   // ---- sim side
   memcpy(m.mj_parent, b.i32("mj_parent", NB), sizeof m.mj_parent);
+  for (int j = 0; j < NB; j++)
+    if (m.mj_parent[j] != TOPO_PARENT[j])
+      throw std::string("model blob's sim tree differs from the topology this library was compiled for "
+                        "(regenerate csrc/tsidb_topology.hpp with model_compiler.py and rebuild)");
   tree_tables(m.mj_parent, NB, m.mj_depth, m.mj_nchild, m.mj_child, m.mj_anc, &m.mj_maxdepth);
   const double *mp = b.f64("mj_pos", NB * 3), *mq = b.f64("mj_quat", NB * 4), *mi = b.f64("mj_inertia", NB * 10);
   for (int j = 0; j < NB; j++) {

@@ -14,6 +14,7 @@
 #pragma once
 #include "tsidb_common.hpp"
 #include "tsidb_tick.hpp" // rdlane
+#include "tsidb_topology.hpp"
 
 namespace tsidb {
 
@@ -45,40 +46,45 @@ __device__ __forceinline__ int sym_idx(int i, int j) { // packed upper index of 
   return a * 6 - a * (a - 1) / 2 + (b - a);
 }
 
-// Cholesky of the 26x26 SPD matrix whose row `lane` is in a[] (lanes >= 26 hold zeros), then
-// x = A^-1 rhs.  Returns this lane's x; spd=false if a pivot is not positive.
+// Solve A x = rhs for the 26x26 SPD matrix whose row `lane` is in a[] (lanes >= 26 hold zeros), where A
+// has the sparsity of a kinematic tree (A[i][j] != 0 only if dof i is an ancestor of dof j or vice
+// versa) - true for the joint-space inertia M and for M + J^T D J with contact/friction rows.
+// Eliminating leaves first (k = 25 .. 0) gives A = U U^T with U upper triangular and NO fill-in, so
+// only ancestor pairs are touched; MJ_DOFANC is a compile-time table, so the unrolled code simply
+// does not contain the zero updates.  U[i][k] ends up in lane i's a[k] (k >= i).
 template <typename T>
 __device__ __forceinline__ T chol26_solve(T (&a)[NV], T rhs, int lane, bool &spd) {
   spd = true;
-  T rd[NV]; // 1 / L[k][k], wave-uniform
+  T rd[NV]; // 1 / U[k][k], wave-uniform
 #pragma unroll
-  for (int k = 0; k < NV; k++) {
+  for (int k = NV - 1; k >= 0; k--) {
     const T akk = rdlane(a[k], k);
     if (!(akk > 0)) spd = false;
     const T rk = rsqrt_t(akk > 0 ? akk : T(1));
     rd[k] = rk;
-    const T lik = lane == k ? akk * rk : a[k] * rk;
-    a[k] = lik;
+    const T uik = lane < k ? a[k] * rk : (lane == k ? akk * rk : T(0));
+    a[k] = uik;
 #pragma unroll
-    for (int j = k + 1; j < NV; j++) a[j] -= lik * rdlane(lik, j);
+    for (int j = 0; j < k; j++)
+      if ((MJ_DOFANC[k] >> j) & 1u) a[j] -= uik * rdlane(uik, j);
   }
-  // y = L^-1 rhs (uniform chain, lane k contributes y_k) fused with X = L^-1 e_lane (column `lane`)
-  T acc = rhs, yv = 0, xr[NV], x = 0;
+  // U y = rhs (k descending; lane k contributes y_k), then U^T x = y (k ascending, wave-uniform)
+  T acc = rhs, y[NV];
 #pragma unroll
-  for (int i = 0; i < NV; i++) {
-    T s0 = lane == i ? T(1) : T(0), s1 = 0;
-#pragma unroll
-    for (int k = 0; k < i; k++) {
-      const T lik = rdlane(a[k], i);
-      if (k & 1) s1 -= lik * xr[k]; else s0 -= lik * xr[k];
-    }
-    xr[i] = (s0 + s1) * rd[i];
-    const T yi = rdlane(acc, i) * rd[i];
-    if (lane == i) yv = yi;
-    acc -= a[i] * yi;
+  for (int k = NV - 1; k >= 0; k--) {
+    y[k] = rdlane(acc, k) * rd[k];
+    acc -= a[k] * y[k];
   }
+  T xs[NV], x = 0;
 #pragma unroll
-  for (int i = 0; i < NV; i++) x += xr[i] * rdlane(yv, i);
+  for (int k = 0; k < NV; k++) {
+    T s0 = y[k];
+#pragma unroll
+    for (int i = 0; i < k; i++)
+      if ((MJ_DOFANC[k] >> i) & 1u) s0 -= rdlane(a[k], i) * xs[i];
+    xs[k] = s0 * rd[k];
+    if (lane == k) x = xs[k];
+  }
   return x;
 }
 

@@ -464,10 +464,43 @@ def compile_model(ref_root: Path, out: Path):
     return ts, sim, c0, sections
 
 
+def emit_topology_header(mj_parent, path: Path):
+    """Compile-time copy of the sim tree's dof ancestry for the register Cholesky (tree-sparse
+    elimination without run-time branches).  tsidb_create refuses a blob whose tree differs."""
+    nb = len(mj_parent)
+    nv = 6 + nb - 1
+    anc_body = []
+    for b in range(nb):
+        a, m = b, 0
+        while a >= 0:
+            m |= 1 << a
+            a = int(mj_parent[a])
+        anc_body.append(m)
+    dofanc = []
+    for k in range(nv):
+        if k < 6:
+            dofanc.append((1 << k) - 1)                       # root block is dense
+        else:
+            m = 0
+            for a in range(nb):
+                if a != k - 5 and (anc_body[k - 5] >> a) & 1:
+                    m |= 0x3F if a == 0 else 1 << (5 + a)
+            dofanc.append(m)
+    txt = ("// GENERATED by tsid_control_amd/model_compiler.py from the sim tree of the compiled model blob.\n"
+           "// MJ_DOFANC[k]: bitmask of the dofs that are strict ancestors of dof k (lower indices).\n"
+           "#pragma once\nnamespace tsidb {\n"
+           f"constexpr int TOPO_NB = {nb};\n"
+           "constexpr int TOPO_PARENT[] = {" + ", ".join(str(int(x)) for x in mj_parent) + "};\n"
+           "constexpr unsigned MJ_DOFANC[] = {" + ", ".join(hex(x) + "u" for x in dofanc) + "};\n"
+           "} // namespace tsidb\n")
+    path.write_text(txt)
+
+
 if __name__ == "__main__":
     ref = Path(sys.argv[1] if len(sys.argv) > 1 else "/root/reference")
     out = Path(sys.argv[2] if len(sys.argv) > 2 else Path(__file__).parent / "assets" / "op3_v1.tsidb")
     ts, sim, c0, sec = compile_model(ref, out)
+    emit_topology_header(sec["mj_parent"], Path(__file__).parent / "csrc" / "tsidb_topology.hpp")
     print("joints:", ts["names"])
     print("total mass (TSID):", ts["inertia"][:, 0].sum(), " (sim):", sum(b["inertia"].mass for b in sim["bodies"]))
     print("hull verts:", len(sim["hull_v"]), "edges:", len(sim["edges"]), "blob bytes:", out.stat().st_size)
