@@ -826,16 +826,17 @@ __device__ void tsid_tick_env(const DevModel<T> &m, TickLds<T> &L, int lane, T *
     const int crow = lane < 6 ? lane : (lane < p ? 6 * c.slot_foot[(lane - 6) / 6] + (lane - 6) % 6 : 0);
 #pragma unroll
     for (int i = 0; i < NV; i++) {
-      T xs = lane == i ? T(1) : T(0);
-      T bs = lane < p ? (isbase ? L.Dyn[crow * LDD + i] : L.Jf[crow * LDF + i]) : T(0);
+      // two partial sums per substitution: four independent FMA chains instead of two
+      T xs = lane == i ? T(1) : T(0), xs1 = 0;
+      T bs = lane < p ? (isbase ? L.Dyn[crow * LDD + i] : L.Jf[crow * LDF + i]) : T(0), bs1 = 0;
 #pragma unroll
       for (int k = 0; k < i; k++) {
         const T lik = rdlane(a[k], i);
-        xs -= lik * jr[k];
-        bs -= lik * bc[k];
+        if (k & 1) { xs1 -= lik * jr[k]; bs1 -= lik * bc[k]; }
+        else { xs -= lik * jr[k]; bs -= lik * bc[k]; }
       }
-      jr[i] = xs * rd[i];
-      bc[i] = bs * rd[i];
+      jr[i] = (xs + xs1) * rd[i];
+      bc[i] = (bs + bs1) * rd[i];
       const T yi = rdlane(acc, i) * rd[i];
       if (lane == i) yv = yi;
       acc -= a[i] * yi;
@@ -904,14 +905,14 @@ __device__ void tsid_tick_env(const DevModel<T> &m, TickLds<T> &L, int lane, T *
           const T beta = T(2) / (v0 * v0 + sigma);
           dkk = alpha >= 0 ? -nrm : nrm;
           // s = v . b_col (lanes > k), w = J_row . v (all lanes)
-          T sb = v0 * bc[k], wj = v0 * jr[k];
+          T sb = v0 * bc[k], wj = v0 * jr[k], sb1 = 0, wj1 = 0;
 #pragma unroll
           for (int i = k + 1; i < NVAR; i++) {
             const T vi = rdlane(bc[i], k);
-            sb += vi * bc[i];
-            wj += vi * jr[i];
+            if (i & 1) { sb1 += vi * bc[i]; wj1 += vi * jr[i]; }
+            else { sb += vi * bc[i]; wj += vi * jr[i]; }
           }
-          sb *= beta; wj *= beta;
+          sb = (sb + sb1) * beta; wj = (wj + wj1) * beta;
           const bool upd = lane > k; // columns <= k are final (their rows >= k are already zero)
           jr[k] -= wj * v0;
           if (upd) bc[k] -= sb * v0;
