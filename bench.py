@@ -169,10 +169,12 @@ def main():
              "newton_iters_mean": float(wc.info[:, 2].float().mean()),
              "single_support_frac": float((wc.contact_active.sum(dim=1) == 1).float().mean())}
 
-    traffic = None
+    traffic = traffic_x2 = None
     tf = ROOT / "profiles" / "pmc_traffic.json"
     if tf.exists() and args.dtype == "f64" and n == 4096:
-        traffic = json.loads(tf.read_text()).get(dom, {}).get("bytes_per_launch")  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+        # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/pmc_profile.sh), committed under profiles/
+        rec = json.loads(tf.read_text()).get(dom, {})
+        traffic, traffic_x2 = rec.get("bytes_per_launch"), rec.get("bytes_per_launch_fetch_x2")
 
     if rank == 0:
         value = world * n * args.steps / el
@@ -186,7 +188,7 @@ def main():
                        "envs_per_gpu": n, "global_envs": n * world, "parallelism": f"env-sharded x{world}, obs all-gather",
                        "qp_failed_envs_last_step": n_bad, "last_step_stats": stats},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_fetch_x2": traffic_x2,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": dom_ms,
                          "k_tick_ms": tick_ms, "k_sim_ms": sim_ms,
                          "valu_frac_nominal": (n * NOMINAL_FLOP_PER_ENV_STEP / ((tick_ms + sim_ms) * 1e-3)) / (VALU_PEAK_TFLOPS[args.dtype] * 1e12)},
