@@ -180,6 +180,63 @@ def test_contact_switching_and_walking_refs_f64(oracle):
     assert seen_single
 
 
+def test_active_set_stress_f64(oracle):
+    """Large velocity/posture perturbations: many inequality rows become active and get dropped again
+    (the register-resident active-set loop's add, partial-step/drop and re-add paths), single and double
+    support mixed.  One tick per env from identical inputs; every env must agree with the oracle."""
+    n = 256
+    wc = make(n, sim_enabled=False)
+    perturb(wc, 21, dq=0.25, dv=1.5)
+    wc.contact_active[::3, 0] = 0          # every third env in right single support
+    wc.contact_active[1::7, 1] = 0         # some in left single support / flight
+    wc.contact_active[(wc.contact_active.sum(dim=1) == 0), 0] = 1
+    st = mirror(wc)
+    wc.tick()
+    iters_o = np.zeros(n, int)
+    for e in range(n):
+        out = oracle.tsid_tick(wc.params, st["q"][e], st["v"][e], st["com_ref"][e], st["posture_ref"][e], st["foot_ref"][e],
+                               st["contact_ref"][e], st["contact_active"][e], st["cop_frames"][e])
+        st["tau"][e], st["dv"][e], st["f"][e], st["status"][e], iters_o[e] = out["tau"], out["dv"], out["f"], out["status"], out["iters"]
+    assert np.array_equal(wc.status.cpu().numpy(), st["status"])
+    ok = st["status"] == 0
+    assert ok.sum() > n // 2
+    assert diff(wc.dv[ok], st["dv"][ok]) < 1e-6 and diff(wc.tau[ok], st["tau"][ok]) < 1e-6
+    assert np.abs(wrench(wc.f.cpu().numpy(), wc.params)[ok] - wrench(st["f"], wc.params)[ok]).max() < 1e-6
+    assert diff(wc.q[ok], st["q"][ok]) < 1e-9
+    it_g = wc.info[:, 0].cpu().numpy()
+    assert it_g.max() >= 8 and (wc.info[:, 1].cpu().numpy() - np.where(st["contact_active"].sum(1) == 2, 18, 12)).max() >= 6
+    # the two solvers walk the same active-set path (same number of outer iterations) on the vast majority
+    assert (it_g[ok] == iters_o[ok]).mean() > 0.9
+
+
+def test_max_iter_status_on_gpu(oracle):
+    wc = make(32, sim_enabled=False, qp_max_iter=3)
+    perturb(wc, 5, dq=0.2, dv=1.0)
+    st = mirror(wc)
+    q0 = wc.q.clone()
+    wc.tick()
+    for e in range(32):
+        out = oracle.tsid_tick(wc.params, st["q"][e], st["v"][e], st["com_ref"][e], st["posture_ref"][e], st["foot_ref"][e],
+                               st["contact_ref"][e], st["contact_active"][e], st["cop_frames"][e])
+        st["status"][e] = out["status"]
+    sg = wc.status.cpu().numpy()
+    assert np.array_equal(sg, st["status"]) and (sg == 3).any()          # HQP_STATUS_MAX_ITER_REACHED
+    assert torch.equal(wc.q[torch.as_tensor(sg == 3)], q0[torch.as_tensor(sg == 3)])
+
+
+def test_env_loop_f32_tracks_oracle(oracle):
+    """f32 path over 25 env steps: states stay within tolerance of the float64 oracle."""
+    wc = make(32, "f32")
+    perturb(wc, 9, dq=0.03, dv=0.03)
+    st = mirror(wc)
+    for i in range(25):
+        wc.step()
+        oracle.env_step_batch(wc.params, st, nthreads=8)
+    assert np.array_equal(wc.status.cpu().numpy(), st["status"])
+    assert diff(wc.q, st["q"]) < 2e-4 and diff(wc.v, st["v"]) < 2e-2
+    assert diff(wc.qpos[:, :7], st["qpos"][:, :7]) < 2e-4
+
+
 def test_walk_update_kernel_equals_host_path():
     """tsidb_walk_update (one kernel) == update_tasks(sample(t)) + com_xy (tensor expressions)."""
     from tsid_control_amd.walk_planner import WalkSchedule
