@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--workload", choices=["walk", "stand"], default="walk")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline budget; 0 disables it")
     ap.add_argument("--cpu-sample", type=int, default=256)
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="run tick and sim back to back on one stream instead of overlapping sim(t) with tick(t+1)")
     return ap.parse_args()
 
 
@@ -124,18 +126,43 @@ def main():
         wc.v[:] = torch.randn(n, 26, dtype=wc.dtype, device=dev) * 0.05
     gather = ObsGather(n, 65, world, wc.dtype, dev)
     total = args.warmup + args.steps
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
+
+    # The sim stage of step t only needs the TSID state tick t produced, and tick t+1 does not depend on
+    # sim t (the reference couples them one way, main.py:192-195): sim(t) runs on a second HIP stream
+    # while tick(t+1) runs on the first.  tick hands its q to the sim through a two-slot buffer; slot
+    # reuse waits on the sim that read it two steps earlier.
+    overlap = not args.no_overlap
+    s_tick = torch.cuda.current_stream(dev)
+    s_sim = torch.cuda.Stream(device=dev) if overlap else s_tick
+    q_hand = [torch.empty_like(wc.q), torch.empty_like(wc.q)]
+    sim_done = [None, None]
 
     def one_step(i, timed_idx=None):
+        par = i & 1
         if sched is not None:
-            t = i * conf.dt
-            sched.apply(wc, t)
-        if timed_idx is None:
-            wc.tick()
-            wc.sim_step()
+            sched.apply(wc, i * conf.dt)
+        e = ev[timed_idx] if timed_idx is not None else None
+        if e: e[0].record(s_tick)
+        wc.tick()
+        if e: e[1].record(s_tick)
+        if overlap:
+            if sim_done[par] is not None:
+                s_tick.wait_event(sim_done[par])
+            q_hand[par].copy_(wc.q)
+            ready = torch.cuda.Event()
+            ready.record(s_tick)
+            with torch.cuda.stream(s_sim):
+                s_sim.wait_event(ready)
+                if e: e[2].record(s_sim)
+                wc.sim_step(q_tsid=q_hand[par])
+                if e: e[3].record(s_sim)
+                sim_done[par] = torch.cuda.Event()
+                sim_done[par].record(s_sim)
         else:
-            e = ev[timed_idx]
-            e[0].record(); wc.tick(); e[1].record(); wc.sim_step(); e[2].record()
+            if e: e[2].record(s_tick)
+            wc.sim_step()
+            if e: e[3].record(s_tick)
         gather(wc.obs)
 
     for i in range(args.warmup):
@@ -156,7 +183,7 @@ def main():
     el = float(elt.item())
 
     tick_ms = sum(e[0].elapsed_time(e[1]) for e in ev) / args.steps
-    sim_ms = sum(e[1].elapsed_time(e[2]) for e in ev) / args.steps
+    sim_ms = sum(e[2].elapsed_time(e[3]) for e in ev) / args.steps
     wsz = 8 if args.dtype == "f64" else 4
     dom, dom_ms, dom_words = ("k_tick", tick_ms, TICK_WORDS) if tick_ms >= sim_ms else ("k_sim", sim_ms, SIM_WORDS)
     alg_bytes = n * dom_words * wsz
@@ -186,6 +213,7 @@ def main():
                                     "update_tasks each tick; TSID tick + sim step)" if args.workload == "walk" else
                                     "cfg2: perturbed stand/balance per GPU"),
                        "envs_per_gpu": n, "global_envs": n * world, "parallelism": f"env-sharded x{world}, obs all-gather",
+                       "streams": "sim(t) overlapped with tick(t+1) on a second HIP stream" if overlap else "single stream",
                        "qp_failed_envs_last_step": n_bad, "last_step_stats": stats},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_fetch_x2": traffic_x2,
