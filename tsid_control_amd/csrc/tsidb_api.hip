@@ -54,8 +54,8 @@ __global__ __launch_bounds__(WAVE) void k_rbd(const DevModel<T> *__restrict__ mp
   rbd_terms<T>(*mp, L, lane);
   for (int i = lane; i < NV * NV; i += WAVE) M[E * NV * NV + i] = L.Dyn[(i / NV) * LDD + i % NV];
   if (lane < NV) hb[E * NV + lane] = L.h[lane];
-  for (int i = lane; i < 3 * NV; i += WAVE) Jcom[E * 3 * NV + i] = L.Jcom[(i / NV) * LDF + i % NV];
-  for (int i = lane; i < 12 * NV; i += WAVE) Jf[E * 12 * NV + i] = L.Jf[(i / NV) * LDF + i % NV];
+  for (int i = lane; i < 3 * NV; i += WAVE) Jcom[E * 3 * NV + i] = L.k.Jcom[(i / NV) * LDF + i % NV];
+  for (int i = lane; i < 12 * NV; i += WAVE) Jf[E * 12 * NV + i] = L.k.Jf[(i / NV) * LDF + i % NV];
   if (lane < 24) oMf[E * 24 + lane] = L.oMf[lane / 12][lane % 12];
   if (lane < 3) com[E * 3 + lane] = L.com[lane];
 }

@@ -20,10 +20,23 @@ namespace tsidb {
 constexpr int SLOT0 = 12; // J columns below 12 always belong to equality constraints
 constexpr int NAS = 34;   // room for the active inequalities (at most n - p = 32)
 
+// LDS plan of k_tick (20.3 KB in float64 -> 8 workgroups per CU).  Three lifetimes share one region:
+//   rigid-body passes:  S, frames, subtree forces/inertias, and per-joint R, p, V, A
+//   task assembly:      the frame / CoM Jacobians take over R, p, V, A's space once the frames are known;
+//                       the task right-hand sides take over the subtree forces' space
+//   active set:         triangular factor, row values, flags take over all of it
 template <typename T>
-struct KinScratch { // rigid-body passes; dead before the QP starts
-  T R[NJ][9], p[NJ][3], S[NV][6], V[NJ][6], A[NJ][6], f[NJ][6], Yc[NJ][10], F[NV][6];
-  T fR[2][9], fp[2][3];
+struct KinScratch {
+  T S[NV][6], fR[2][9], fp[2][3];
+  union {
+    T f[NJ][6];
+    struct { T arhs[4][6], acomr[3], apost[NA]; }; // a_des - drift: contact LF/RF, foot LF/RF; CoM; posture
+  };
+  T Yc[NJ][10];
+  union {
+    struct { T R[NJ][9], p[NJ][3], V[NJ][6], A[NJ][6]; };
+    struct { T Jf[12 * LDF], Jcom[3 * LDF]; }; // frame Jacobians LOCAL (LF rows 0..5, RF 6..11), CoM Jacobian
+  };
 };
 
 template <typename T>
@@ -31,6 +44,7 @@ struct ActiveSetLds { // dual active-set bookkeeping; J itself lives in register
   T Ra[NAS * (NAS + 1) / 2 + 2]; // packed upper-triangular factor of the active inequality normals
   T Rinv[NAS + 2];               // reciprocal diagonal
   T s[160];
+  T actp[3][NA];                 // partial sums of the actuation rows [M_a | -J_a^T] x (three column ranges)
   int slot[NAS + 2], A[NAS + 2], Aold[NAS + 2];
   unsigned char cstate[160];     // bit0: in the active set, bit1: excluded for this outer iteration
 };
@@ -42,20 +56,15 @@ struct TickLds {
     ActiveSetLds<T> as;
   };
   T Dyn[NV * LDD]; // row r = [M[r][0:26] | -Jc[:, r]^T]  (rows 0..5: base dynamics, 6..25: actuation)
-  T Jf[12 * LDF];  // frame Jacobians, LOCAL (LF rows 0..5, RF rows 6..11)
-  T Jcom[3 * LDF];
   T h[NV];
   T x[NVAR];
-  T actp[3][NA]; // partial sums of the actuation rows [M_a | -J_a^T] x (three column ranges)
-  T fstage[24];
-  T arhs[4][6]; // a_des - drift: contact LF, contact RF, foot LF, foot RF
-  T acomr[3], apost[NA];
   T oMf[2][12]; // frame placement: R row-major, p (world)
   T vf[2][6], af[2][6];
   T com[3], vcom[3], acomd[3];
   T qs[NQ], vs[NV];
-  T vstage[NV];
 };
+static_assert(sizeof(ActiveSetLds<double>) <= sizeof(KinScratch<double>), "active-set state must fit the scratch region");
+static_assert(sizeof(TickLds<double>) <= 20480, "k_tick must fit 8 workgroups per CU");
 
 template <typename T> __device__ __forceinline__ T bcast(T v, int src) { return __shfl(v, src, WAVE); }
 
@@ -207,6 +216,7 @@ __device__ void rbd_terms(const DevModel<T> &m, TickLds<T> &L, int lane) {
   }
   // ---- per dof: bias, F = Yc S, mass-matrix entries, CoM Jacobian column
   const T invm = T(1) / m.mass;
+  T jc[3] = {0, 0, 0};
   if (lane < NV) {
     const int k = lane, jk = k < 6 ? 0 : k - 5;
     T Sk[6], Fk[6];
@@ -217,11 +227,7 @@ __device__ void rbd_terms(const DevModel<T> &m, TickLds<T> &L, int lane) {
     for (int i = 0; i < 6; i++) hk += Sk[i] * K.f[jk][i];
     L.h[k] = hk;
     yo_mul(K.Yc[jk], Sk, Fk);
-#pragma unroll
-    for (int i = 0; i < 6; i++) K.F[k][i] = Fk[i];
-    L.Jcom[0 * LDF + k] = Fk[0] * invm;
-    L.Jcom[1 * LDF + k] = Fk[1] * invm;
-    L.Jcom[2 * LDF + k] = Fk[2] * invm;
+    jc[0] = Fk[0] * invm; jc[1] = Fk[1] * invm; jc[2] = Fk[2] * invm; // CoM Jacobian column (written below)
     // M[i][k] = S_i . F_k for every dof i on the path root..k (ancestor bitmask; loads independent)
     for (unsigned mk = dofanc; mk; mk &= mk - 1) {
       const int a = __ffs(mk) - 1;
@@ -286,15 +292,16 @@ __device__ void rbd_terms(const DevModel<T> &m, TickLds<T> &L, int lane) {
         mat3Tvec(K.fR[f], &K.S[k][3], col + 3);
       }
 #pragma unroll
-      for (int i = 0; i < 6; i++) L.Jf[(6 * f + i) * LDF + k] = col[i];
+      for (int i = 0; i < 6; i++) K.Jf[(6 * f + i) * LDF + k] = col[i];
     }
+#pragma unroll
+    for (int i = 0; i < 3; i++) K.Jcom[i * LDF + k] = jc[i];
   }
   {
     T vk = lane < NV ? L.vs[lane] : T(0);
 #pragma unroll
     for (int i = 0; i < 3; i++) {
-      T part = lane < NV ? L.Jcom[i * LDF + lane] * vk : T(0);
-      T tot = wave_sum(part);
+      T tot = wave_sum(lane < NV ? jc[i] * vk : T(0));
       if (lane == 0) L.vcom[i] = tot;
     }
   }
@@ -413,7 +420,7 @@ __device__ __forceinline__ void act_partials(TickLds<T> &L, int n, int lane) {
       a1 += L.Dyn[(6 + j) * LDD + e + 1] * L.x[e + 1];
     }
     if (e < e1) a0 += L.Dyn[(6 + j) * LDD + e] * L.x[e];
-    L.actp[part][j] = a0 + a1;
+    L.as.actp[part][j] = a0 + a1;
   }
 }
 
@@ -427,7 +434,7 @@ __device__ __forceinline__ T row_eval(const RowDesc<T> &d, const TickLds<T> &L) 
     for (int pt = 0; pt < 4; pt++)
       val += d.cf[0] * L.x[d.idx + 3 * pt] + d.cf[1] * L.x[d.idx + 3 * pt + 1] + d.cf[2] * L.x[d.idx + 3 * pt + 2];
   } else if (d.kind == 2) {
-    val = L.actp[0][d.idx] + L.actp[1][d.idx] + L.actp[2][d.idx];
+    val = L.as.actp[0][d.idx] + L.as.actp[1][d.idx] + L.as.actp[2][d.idx];
   } else if (d.kind == 3) {
     val = L.x[d.idx];
   }
@@ -740,22 +747,22 @@ __device__ void tsid_tick_env(const DevModel<T> &m, TickLds<T> &L, int lane, T *
   const int n = c.n;
 
   // ---- task right-hand sides
-  if (lane < 2) se3_rhs(L, lane, contact_ref + 12 * lane, 12, m.params[P_KP_CONTACT], m.params[P_KD_CONTACT], L.arhs[lane]);
-  else if (lane < 4) se3_rhs(L, lane - 2, foot_ref + 24 * (lane - 2), 24, m.params[P_KP_FOOT], m.params[P_KD_FOOT], L.arhs[lane]);
+  if (lane < 2) se3_rhs(L, lane, contact_ref + 12 * lane, 12, m.params[P_KP_CONTACT], m.params[P_KD_CONTACT], L.k.arhs[lane]);
+  else if (lane < 4) se3_rhs(L, lane - 2, foot_ref + 24 * (lane - 2), 24, m.params[P_KP_FOOT], m.params[P_KD_FOOT], L.k.arhs[lane]);
   else if (lane < 7) {
     const int i = lane - 4;
-    L.acomr[i] = -m.params[P_KP_COM] * (L.com[i] - com_ref[i]) - m.params[P_KD_COM] * (L.vcom[i] - com_ref[3 + i]) +
+    L.k.acomr[i] = -m.params[P_KP_COM] * (L.com[i] - com_ref[i]) - m.params[P_KD_COM] * (L.vcom[i] - com_ref[3 + i]) +
                  com_ref[6 + i] - L.acomd[i];
   } else if (lane >= 32 && lane < 32 + NA) {
     const int r = lane - 32;
-    L.apost[r] = -m.params[P_KP_POSTURE + r] * (L.qs[7 + r] - posture_ref[r]) - m.params[P_KD_POSTURE + r] * L.vs[6 + r];
+    L.k.apost[r] = -m.params[P_KP_POSTURE + r] * (L.qs[7 + r] - posture_ref[r]) - m.params[P_KD_POSTURE + r] * L.vs[6 + r];
   }
   // ---- right block of the dynamics rows: Dyn[r][26 + 12 s + cc] = -sum_i T[i][cc] Jf[6 f + i][r]
   for (int idx = lane; idx < NV * 12 * c.nslot; idx += WAVE) {
     const int r = idx / (12 * c.nslot), cc = idx % (12 * c.nslot), s = cc / 12, e = cc % 12, f = c.slot_foot[s];
     T a = 0;
 #pragma unroll
-    for (int i = 0; i < 6; i++) a += m.Tgen[i][e] * L.Jf[(6 * f + i) * LDF + r];
+    for (int i = 0; i < 6; i++) a += m.Tgen[i][e] * L.k.Jf[(6 * f + i) * LDF + r];
     L.Dyn[r * LDD + NV + cc] = -a;
   }
   __syncthreads(); // kinematics scratch is dead from here on
@@ -767,16 +774,16 @@ __device__ void tsid_tick_env(const DevModel<T> &m, TickLds<T> &L, int lane, T *
   {
     const int i = lane < NV ? lane : 0;
 #pragma unroll
-    for (int r = 0; r < 12; r++) jt[r] = lane < NV ? L.Jf[r * LDF + i] : T(0);
+    for (int r = 0; r < 12; r++) jt[r] = lane < NV ? L.k.Jf[r * LDF + i] : T(0);
 #pragma unroll
-    for (int r = 0; r < 3; r++) jt[12 + r] = lane < NV ? L.Jcom[r * LDF + i] : T(0);
+    for (int r = 0; r < 3; r++) jt[12 + r] = lane < NV ? L.k.Jcom[r * LDF + i] : T(0);
   }
   T gi = 0;
 #pragma unroll
-  for (int r = 0; r < 12; r++) gi -= w_foot * jt[r] * L.arhs[2 + r / 6][r % 6];
+  for (int r = 0; r < 12; r++) gi -= w_foot * jt[r] * L.k.arhs[2 + r / 6][r % 6];
 #pragma unroll
-  for (int r = 0; r < 3; r++) gi -= w_com * jt[12 + r] * L.acomr[r];
-  if (lane >= 6 && lane < NV) gi -= w_post * L.apost[lane - 6];
+  for (int r = 0; r < 3; r++) gi -= w_com * jt[12 + r] * L.k.acomr[r];
+  if (lane >= 6 && lane < NV) gi -= w_post * L.k.apost[lane - 6];
   if (lane >= NV) gi = 0;
 #pragma unroll
   for (int j = 0; j < NV; j++) {
@@ -828,7 +835,7 @@ __device__ void tsid_tick_env(const DevModel<T> &m, TickLds<T> &L, int lane, T *
     for (int i = 0; i < NV; i++) {
       // two partial sums per substitution: four independent FMA chains instead of two
       T xs = lane == i ? T(1) : T(0), xs1 = 0;
-      T bs = lane < p ? (isbase ? L.Dyn[crow * LDD + i] : L.Jf[crow * LDF + i]) : T(0), bs1 = 0;
+      T bs = lane < p ? (isbase ? L.Dyn[crow * LDD + i] : L.k.Jf[crow * LDF + i]) : T(0), bs1 = 0;
 #pragma unroll
       for (int k = 0; k < i; k++) {
         const T lik = rdlane(a[k], i);
@@ -852,7 +859,7 @@ __device__ void tsid_tick_env(const DevModel<T> &m, TickLds<T> &L, int lane, T *
     }
     c2 += T(c.nslot) * m.Jf0_trace;
     if (lane < 6) ck += L.h[lane];
-    else if (lane < p) ck -= L.arhs[c.slot_foot[(lane - 6) / 6]][(lane - 6) % 6];
+    else if (lane < p) ck -= L.k.arhs[c.slot_foot[(lane - 6) / 6]][(lane - 6) % 6];
     // force rows: J0 row of the constant block; B rows 26.. = L_f^-1 (-Jc)^T for the base-dynamics columns
 #pragma unroll
     for (int j = NV; j < NVAR; j++) { jr[j] = 0; bc[j] = 0; }
@@ -988,7 +995,7 @@ __device__ void tsid_tick_env(const DevModel<T> &m, TickLds<T> &L, int lane, T *
     for (int s = 0; s < c.nslot; s++)
       if (c.slot_foot[s] == fo) val = L.x[NV + 12 * s + e];
     fout[lane] = val;
-    L.fstage[lane] = val; // staged for the CoP
+    L.as.s[lane] = val; // staged for the CoP
   }
   if (lane < NA) {
     T t = L.h[6 + lane];
@@ -1008,7 +1015,7 @@ __device__ void tsid_tick_env(const DevModel<T> &m, TickLds<T> &L, int lane, T *
       for (int fo = 0; fo < 2; fo++) {
         T w[6] = {0, 0, 0, 0, 0, 0};
         for (int e = 0; e < 12; e++) {
-          T fe = L.fstage[12 * fo + e];
+          T fe = L.as.s[12 * fo + e];
 #pragma unroll
           for (int i = 0; i < 6; i++) w[i] += m.Tgen[i][e] * fe;
         }
@@ -1040,12 +1047,12 @@ __device__ void tsid_tick_env(const DevModel<T> &m, TickLds<T> &L, int lane, T *
       const T vv = L.vs[lane], dd = L.x[lane];
       vm = dt * (vv + T(0.5) * dt * dd);
       L.vs[lane] = vv + dt * dd;
-      L.vstage[lane] = vm;
+      L.as.Ra[lane] = vm;
     }
     __syncthreads();
     if (lane >= 6 && lane < NV) L.qs[lane + 1] += vm;
     if (lane == 0) {
-      const T *vl = &L.vstage[0], *w = &L.vstage[3];
+      const T *vl = &L.as.Ra[0], *w = &L.as.Ra[3];
       const T th2 = dot3(w, w), th = sqrt(th2);
       const T small = sizeof(T) == 8 ? T(1e-8) : T(1e-4);
       T b, cc, sh, ch;
