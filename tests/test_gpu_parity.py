@@ -213,6 +213,30 @@ def test_active_set_stress_f64(oracle):
     assert (it_g[ok] == iters_o[ok]).mean() > 0.7 and np.abs(it_g[ok] - iters_o[ok]).max() <= 8
 
 
+def test_flight_and_single_support_ticks(oracle):
+    """All four contact configurations (both, left only, right only, none) in one batch."""
+    n = 64
+    wc = make(n, sim_enabled=False)
+    perturb(wc, 33, dq=0.1, dv=0.5)
+    wc.contact_active[:, 0] = (torch.arange(n, device=wc.device) % 4 < 2).to(torch.uint8)
+    wc.contact_active[:, 1] = (torch.arange(n, device=wc.device) % 2 == 0).to(torch.uint8)
+    st = mirror(wc)
+    wc.tick()
+    for e in range(n):
+        out = oracle.tsid_tick(wc.params, st["q"][e], st["v"][e], st["com_ref"][e], st["posture_ref"][e], st["foot_ref"][e],
+                               st["contact_ref"][e], st["contact_active"][e], st["cop_frames"][e])
+        st["tau"][e], st["dv"][e], st["f"][e], st["status"][e] = out["tau"], out["dv"], out["f"], out["status"]
+    assert np.array_equal(wc.status.cpu().numpy(), st["status"])
+    ok = st["status"] == 0
+    assert ok.sum() >= n // 2
+    assert np.allclose(wc.dv.cpu().numpy()[ok], st["dv"][ok], rtol=1e-7, atol=1e-7)
+    assert np.allclose(wc.tau.cpu().numpy()[ok], st["tau"][ok], rtol=1e-7, atol=1e-7)
+    f = wc.f.cpu().numpy()
+    ca = st["contact_active"]
+    assert np.all(f[ca[:, 0] == 0, :12] == 0) and np.all(f[ca[:, 1] == 0, 12:] == 0)   # no force on a lifted foot
+    assert (wc.info[:, 1].cpu().numpy()[ok] >= 6 + 6 * ca.sum(1)[ok]).all()
+
+
 def test_max_iter_status_on_gpu(oracle):
     wc = make(32, sim_enabled=False, qp_max_iter=3)
     perturb(wc, 5, dq=0.2, dv=1.0)

@@ -17,7 +17,7 @@
 
 namespace tsidb {
 
-constexpr int SLOT0 = 12; // J columns below 12 always belong to equality constraints
+constexpr int SLOT0 = 6;  // J columns below 6 always belong to equality constraints (p = 6 with no contact)
 constexpr int NAS = 34;   // room for the active inequalities (at most n - p = 32)
 
 // LDS plan of k_tick (20.3 KB in float64 -> 8 workgroups per CU).  Three lifetimes share one region:
