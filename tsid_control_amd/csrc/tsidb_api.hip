@@ -23,9 +23,16 @@ __global__ __launch_bounds__(WAVE) void k_tick(const DevModel<T> *__restrict__ m
   const int e = blockIdx.x, lane = threadIdx.x;
   if (e >= n) return;
   const size_t E = (size_t)e;
-  tsid_tick_env<T>(*mp, L, lane, q + E * NQ, v + E * NV, com_ref + E * 9, posture_ref + E * NA, foot_ref + E * 48,
-                   contact_ref + E * 24, cact + E * 2, cop_frames ? cop_frames + E * 24 : nullptr, tau + E * NA,
-                   dv + E * NV, f + E * 24, status + e, obs ? obs + E * NOBS : nullptr, info ? info + E * 4 : nullptr);
+  // the contact configuration is known before anything is computed: run the variant compiled for it
+  const int nslot = (cact[E * 2] != 0) + (cact[E * 2 + 1] != 0);
+#define TSIDB_TICK_ARGS                                                                                                    \
+  *mp, L, lane, q + E * NQ, v + E * NV, com_ref + E * 9, posture_ref + E * NA, foot_ref + E * 48, contact_ref + E * 24,  \
+      cact + E * 2, cop_frames ? cop_frames + E * 24 : nullptr, tau + E * NA, dv + E * NV, f + E * 24, status + e,       \
+      obs ? obs + E * NOBS : nullptr, info ? info + E * 4 : nullptr
+  if (nslot == 2) tsid_tick_env<T, 2>(TSIDB_TICK_ARGS);
+  else if (nslot == 1) tsid_tick_env<T, 1>(TSIDB_TICK_ARGS);
+  else tsid_tick_env<T, 0>(TSIDB_TICK_ARGS);
+#undef TSIDB_TICK_ARGS
   if (frames && lane < 24) frames[E * 24 + lane] = L.oMf[lane / 12][lane % 12];
 }
 

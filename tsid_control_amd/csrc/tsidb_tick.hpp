@@ -17,7 +17,6 @@
 
 namespace tsidb {
 
-constexpr int SLOT0 = 6;  // J columns below 6 always belong to equality constraints (p = 6 with no contact)
 constexpr int NAS = 34;   // room for the active inequalities (at most n - p = 32)
 
 // LDS plan of k_tick (20.3 KB in float64 -> 8 workgroups per CU).  Three lifetimes share one region:
@@ -452,10 +451,10 @@ __device__ __forceinline__ double rdlane_dyn(double v, int src) {
   return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
 }
 // jr[cidx] for a wave-uniform run-time column index (registers cannot be indexed dynamically)
-template <typename T> __device__ __forceinline__ T col_select(const T (&jr)[NVAR], int cidx) {
+template <typename T, int PP, int NN> __device__ __forceinline__ T col_select(const T (&jr)[NN], int cidx) {
   T r = 0;
 #pragma unroll
-  for (int j = SLOT0; j < NVAR; j++) r = (j == cidx) ? jr[j] : r;
+  for (int j = PP; j < NN; j++) r = (j == cidx) ? jr[j] : r;
   return r;
 }
 
@@ -467,11 +466,12 @@ template <typename T> __device__ __forceinline__ T col_select(const T (&jr)[NVAR
 // v_readlane (sparse normals) or DPP wave sums (dense normals).  Only the small triangular factor of
 // the active inequality normals, the row values and flags live in LDS.  The multipliers of the
 // equality constraints are not tracked (nothing downstream reads them).
-template <typename T>
-__device__ __forceinline__ int qp_active_regs(const DevModel<T> &m, TickLds<T> &L, QpCtx<T> &c, int lane, T (&jr)[NVAR], T &xl,
-                                              const RowDesc<T> (&rd)[3], T c1, T c2, int max_iter, int &iter_out) {
+template <typename T, int NS>
+__device__ __forceinline__ int qp_active_regs(const DevModel<T> &m, TickLds<T> &L, QpCtx<T> &c, int lane, T (&jr)[NV + 12 * NS],
+                                              T &xl, const RowDesc<T> (&rd)[3], T c1, T c2, int max_iter, int &iter_out) {
   ActiveSetLds<T> &S = L.as;
-  const int n = c.n, p = c.p;
+  constexpr int NN = NV + 12 * NS, PP = 6 + 6 * NS;
+  const int n = NN, p = PP;
   const T INF = Eps<T>::inf;
   unsigned long long freem = ((1ull << n) - 1ull) & ~((1ull << p) - 1ull);
   int na = 0;
@@ -561,13 +561,13 @@ __device__ __forceinline__ int qp_active_regs(const DevModel<T> &m, TickLds<T> &
         T dl = 0;
         if (sparse) {
 #pragma unroll
-          for (int j = SLOT0; j < NVAR; j++) {
+          for (int j = PP; j < NN; j++) {
             const T tmp = sc[0] * rdlane_dyn(jr[j], si[0]) + sc[1] * rdlane_dyn(jr[j], si[1]) + sc[2] * rdlane_dyn(jr[j], si[2]);
             if (lane == j) dl = tmp;
           }
         } else {
 #pragma unroll
-          for (int j = SLOT0; j < NVAR; j++) {
+          for (int j = PP; j < NN; j++) {
             const T tmp = wave_sum(npl * jr[j]);
             if (lane == j) dl = tmp;
           }
@@ -588,13 +588,13 @@ __device__ __forceinline__ int qp_active_regs(const DevModel<T> &m, TickLds<T> &
             const T vl = lane == cstar ? v0 : dfree;
             T w = 0;
 #pragma unroll
-            for (int j = SLOT0; j < NVAR; j++) w += jr[j] * rdlane(vl, j);
+            for (int j = PP; j < NN; j++) w += jr[j] * rdlane(vl, j);
             w *= beta;
 #pragma unroll
-            for (int j = SLOT0; j < NVAR; j++) jr[j] -= w * rdlane(vl, j);
+            for (int j = PP; j < NN; j++) jr[j] -= w * rdlane(vl, j);
             dnew = alpha >= 0 ? -nrm : nrm;
           }
-          z = lane < n ? col_select(jr, cstar) * dnew : T(0);
+          z = lane < n ? col_select<T, PP, NN>(jr, cstar) * dnew : T(0);
           zz = wave_sum(z * z);
           znp = dnew * dnew;
         }
@@ -677,10 +677,10 @@ __device__ __forceinline__ int qp_active_regs(const DevModel<T> &m, TickLds<T> &
             }
             if (lane == 0) { S.Ra[rcol(co) + j] = diag; S.Ra[rcol(co) + j + 1] = 0; }
             const int sa = S.slot[j], sb = S.slot[j + 1];
-            const T ta = col_select(jr, sa), tb = col_select(jr, sb);
+            const T ta = col_select<T, PP, NN>(jr, sa), tb = col_select<T, PP, NN>(jr, sb);
             const T n1 = ta * cc + tb * ss, n2 = xny * (n1 + ta) - tb;
 #pragma unroll
-            for (int jj = SLOT0; jj < NVAR; jj++) jr[jj] = (jj == sa) ? n1 : ((jj == sb) ? n2 : jr[jj]);
+            for (int jj = PP; jj < NN; jj++) jr[jj] = (jj == sa) ? n1 : ((jj == sb) ? n2 : jr[jj]);
             __syncthreads();
           }
           for (int k = qq + 1; k < na; k++) { // shift the packed columns left
@@ -721,8 +721,178 @@ __device__ __forceinline__ int qp_active_regs(const DevModel<T> &m, TickLds<T> &
   return status;
 }
 
+// QP of one contact configuration (NS = number of feet in contact: variables 26 + 12 NS, equalities
+// 6 + 6 NS) from the Cholesky factor of the dv block onwards; sized at compile time so that the
+// register-resident rows/columns and every unrolled loop carry no padding for absent contacts.
+template <typename T, int NS>
+__device__ __forceinline__ void tick_qp(const DevModel<T> &m, TickLds<T> &L, QpCtx<T> &c, int lane, const T (&a)[NV],
+                                        const T (&rd)[NV], T gi, T c1, bool spd, int &qp_status, int &qp_iters) {
+  // ---- three forward substitutions with L share its broadcast entries:
+  //   y  = L^-1 (-g)                      (uniform, lane i contributes y_i)
+  //   xr = L^-1 e_lane                    (column `lane` of L^-1 = row `lane` of J0 = L^-T)
+  //   bc = L^-1 CE[lane][0:26]^T          (column `lane` of B = J0^T CE^T, lanes < p)
+  constexpr int NN = NV + 12 * NS, PP = 6 + 6 * NS; // variables / equality constraints of this contact configuration
+  const int p = PP, n = NN;
+  T bc[NN], jr[NN];
+  {
+    T acc = -gi;
+    T yv = 0;
+    // CE row `lane`: base dynamics rows come from Dyn, contact motion rows from the frame Jacobians
+    const bool isbase = lane < 6;
+    const int crow = lane < 6 ? lane : (lane < p ? 6 * c.slot_foot[(lane - 6) / 6] + (lane - 6) % 6 : 0);
+#pragma unroll
+    for (int i = 0; i < NV; i++) {
+      // two partial sums per substitution: four independent FMA chains instead of two
+      T xs = lane == i ? T(1) : T(0), xs1 = 0;
+      T bs = lane < p ? (isbase ? L.Dyn[crow * LDD + i] : L.k.Jf[crow * LDF + i]) : T(0), bs1 = 0;
+#pragma unroll
+      for (int k = 0; k < i; k++) {
+        const T lik = rdlane(a[k], i);
+        if (k & 1) { xs1 -= lik * jr[k]; bs1 -= lik * bc[k]; }
+        else { xs -= lik * jr[k]; bs -= lik * bc[k]; }
+      }
+      jr[i] = (xs + xs1) * rd[i];
+      bc[i] = (bs + bs1) * rd[i];
+      const T yi = rdlane(acc, i) * rd[i];
+      if (lane == i) yv = yi;
+      acc -= a[i] * yi;
+    }
+    // x0 = L^-T y ; c_k = ce0_k + B[:,k] . y ; trace(J0)
+    T x0 = 0, c2 = 0, ck = 0;
+#pragma unroll
+    for (int i = 0; i < NV; i++) {
+      const T yi = rdlane(yv, i);
+      x0 += jr[i] * yi;
+      ck += bc[i] * yi;
+      c2 += rdlane(jr[i], i);
+    }
+    c2 += T(c.nslot) * m.Jf0_trace;
+    if (lane < 6) ck += L.h[lane];
+    else if (lane < p) ck -= L.k.arhs[c.slot_foot[(lane - 6) / 6]][(lane - 6) % 6];
+    // force rows: J0 row of the constant block; B rows 26.. = L_f^-1 (-Jc)^T for the base-dynamics columns
+#pragma unroll
+    for (int j = NV; j < NN; j++) { jr[j] = 0; bc[j] = 0; }
+    if (lane >= NV && lane < n) {
+#pragma unroll
+      for (int i = 0; i < NV; i++) jr[i] = 0;
+      const int e = (lane - NV) % 12, sl = (lane - NV) / 12;
+#pragma unroll
+      for (int s2 = 0; s2 < NS; s2++)
+#pragma unroll
+        for (int b = 0; b < 12; b++)
+          if (s2 == sl && b >= e) jr[NV + 12 * s2 + b] = m.Jf0[e][b];
+    }
+    if (lane >= n) {
+#pragma unroll
+      for (int i = 0; i < NV; i++) jr[i] = 0;
+    }
+    if (lane < 6) {
+#pragma unroll
+      for (int s2 = 0; s2 < NS; s2++) {
+        T ce[12];
+#pragma unroll
+        for (int b = 0; b < 12; b++) ce[b] = L.Dyn[lane * LDD + NV + 12 * s2 + b];
+#pragma unroll
+        for (int e = 0; e < 12; e++) {
+          T sacc = 0;
+#pragma unroll
+          for (int b = 0; b <= e; b++) sacc += m.Jf0[b][e] * ce[b];
+          bc[NV + 12 * s2 + e] = sacc;
+        }
+      }
+    }
+    TSIDB_STAMP(5);
+    // ---- Householder QR of B (columns in lanes 0..p-1) applied to J (rows in lanes 0..n-1)
+    T R_norm = 1;
+    bool degenerate = false;
+#pragma unroll
+    for (int k = 0; k < PP; k++) {
+      {
+        // lane k owns column k: alpha, tail norm, reflector scale
+        T sig = 0;
+#pragma unroll
+        for (int i = k + 1; i < NN; i++) sig += bc[i] * bc[i];
+        const T alpha = rdlane(bc[k], k), sigma = rdlane(sig, k);
+        T dkk = alpha;
+        if (sigma > 0) {
+          const T nrm = sqrt(alpha * alpha + sigma);
+          const T v0 = alpha + (alpha >= 0 ? nrm : -nrm);
+          const T beta = T(2) / (v0 * v0 + sigma);
+          dkk = alpha >= 0 ? -nrm : nrm;
+          // s = v . b_col (lanes > k), w = J_row . v (all lanes)
+          T sb = v0 * bc[k], wj = v0 * jr[k], sb1 = 0, wj1 = 0;
+#pragma unroll
+          for (int i = k + 1; i < NN; i++) {
+            const T vi = rdlane(bc[i], k);
+            if (i & 1) { sb1 += vi * bc[i]; wj1 += vi * jr[i]; }
+            else { sb += vi * bc[i]; wj += vi * jr[i]; }
+          }
+          sb = (sb + sb1) * beta; wj = (wj + wj1) * beta;
+          const bool upd = lane > k; // columns <= k are final (their rows >= k are already zero)
+          jr[k] -= wj * v0;
+          if (upd) bc[k] -= sb * v0;
+#pragma unroll
+          for (int i = k + 1; i < NN; i++) {
+            const T vi = rdlane(bc[i], k); // lane k's column is untouched until the loop ends
+            jr[i] -= wj * vi;
+            if (upd) bc[i] -= sb * vi;
+          }
+          if (lane == k) {
+            bc[k] = dkk;
+#pragma unroll
+            for (int i = k + 1; i < NN; i++) bc[i] = 0;
+          }
+        }
+        const T ad = fabs(dkk);
+        if (ad <= Eps<T>::v * R_norm) degenerate = true;
+        if (ad > R_norm) R_norm = ad;
+      }
+    }
+    // ---- R^T t = -c (forward), x = x0 + J[:, :p] t  (the equality multipliers u = R^-1 t are not needed)
+    T tacc = -ck, tv[PP];
+#pragma unroll
+    for (int i = 0; i < PP; i++) {
+      tv[i] = rdlane(tacc, i) / rdlane(bc[i], i);
+      tacc -= bc[i] * tv[i];
+    }
+    T xeq = lane < NV ? x0 : T(0);
+#pragma unroll
+    for (int k = 0; k < PP; k++) xeq += jr[k] * tv[k];
+    TSIDB_STAMP(6);
+    // ---- first feasibility sweep straight from registers' result; J / R go to LDS only if the
+    //      active-set iterations are actually needed
+    if (lane < n) L.x[lane] = xeq;
+    __syncthreads();
+    c.iq = p;
+    c.R_norm = R_norm;
+    int iters = 1;
+    int status = -1;
+    if (!spd) status = 2;
+    else if (degenerate) { status = 4; iters = 0; }
+    RowDesc<T> rdesc[3];
+#pragma unroll
+    for (int rr = 0; rr < 3; rr++) rdesc[rr] = row_desc(m, L, c, lane + WAVE * rr);
+    if (status < 0) {
+      act_partials(L, n, lane);
+      __syncthreads();
+      T psi = 0;
+#pragma unroll
+      for (int rr = 0; rr < 3; rr++)
+        if (lane + WAVE * rr < c.nin) {
+          const T sv = row_eval(rdesc[rr], L);
+          psi += sv < 0 ? sv : T(0);
+        }
+      psi = wave_sum(psi);
+      if (fabs(psi) <= T(c.nin) * T(2.220446049250313e-16) * c1 * c2 * T(100)) status = 0;
+    }
+    if (status < 0) status = qp_active_regs<T, NS>(m, L, c, lane, jr, xeq, rdesc, c1, c2, (int)m.params[P_MAX_ITER], iters);
+    qp_status = status;
+    qp_iters = iters;
+  }
+}
+
 // --------------------------------------------------------------------------- the tick
-template <typename T>
+template <typename T, int NS>
 __device__ void tsid_tick_env(const DevModel<T> &m, TickLds<T> &L, int lane, T *q, T *v, const T *com_ref,
                               const T *posture_ref, const T *foot_ref, const T *contact_ref,
                               const uint8_t *cact, const T *cop_frames, T *tau, T *dv, T *fout, int *status_out,
@@ -736,14 +906,13 @@ __device__ void tsid_tick_env(const DevModel<T> &m, TickLds<T> &L, int lane, T *
   TSIDB_STAMP(1);
 
   QpCtx<T> c;
-  c.nslot = 0;
-  c.slot_foot[0] = c.slot_foot[1] = -1;
-  const int act0 = cact[0] != 0, act1 = cact[1] != 0;
-  if (act0) c.slot_foot[c.nslot++] = 0;
-  if (act1) c.slot_foot[c.nslot++] = 1;
-  c.n = NV + 12 * c.nslot;
-  c.p = 6 + 6 * c.nslot;
-  c.nin = 34 * c.nslot + 2 * NA + 2 * NV;
+  const int act0 = cact[0] != 0, act1 = cact[1] != 0; // the caller dispatched on act0 + act1 == NS
+  c.nslot = NS;
+  c.slot_foot[0] = NS == 2 ? 0 : (NS == 1 ? (act0 ? 0 : 1) : -1);
+  c.slot_foot[1] = NS == 2 ? 1 : -1;
+  c.n = NV + 12 * NS;
+  c.p = 6 + 6 * NS;
+  c.nin = 34 * NS + 2 * NA + 2 * NV;
   const int n = c.n;
 
   // ---- task right-hand sides
@@ -819,171 +988,7 @@ __device__ void tsid_tick_env(const DevModel<T> &m, TickLds<T> &L, int lane, T *
     for (int j = k + 1; j < NV; j++) a[j] -= lik * rdlane(lik, j);
   }
   TSIDB_STAMP(4);
-  // ---- three forward substitutions with L share its broadcast entries:
-  //   y  = L^-1 (-g)                      (uniform, lane i contributes y_i)
-  //   xr = L^-1 e_lane                    (column `lane` of L^-1 = row `lane` of J0 = L^-T)
-  //   bc = L^-1 CE[lane][0:26]^T          (column `lane` of B = J0^T CE^T, lanes < p)
-  const int p = c.p;
-  T bc[NVAR], jr[NVAR];
-  {
-    T acc = -gi;
-    T yv = 0;
-    // CE row `lane`: base dynamics rows come from Dyn, contact motion rows from the frame Jacobians
-    const bool isbase = lane < 6;
-    const int crow = lane < 6 ? lane : (lane < p ? 6 * c.slot_foot[(lane - 6) / 6] + (lane - 6) % 6 : 0);
-#pragma unroll
-    for (int i = 0; i < NV; i++) {
-      // two partial sums per substitution: four independent FMA chains instead of two
-      T xs = lane == i ? T(1) : T(0), xs1 = 0;
-      T bs = lane < p ? (isbase ? L.Dyn[crow * LDD + i] : L.k.Jf[crow * LDF + i]) : T(0), bs1 = 0;
-#pragma unroll
-      for (int k = 0; k < i; k++) {
-        const T lik = rdlane(a[k], i);
-        if (k & 1) { xs1 -= lik * jr[k]; bs1 -= lik * bc[k]; }
-        else { xs -= lik * jr[k]; bs -= lik * bc[k]; }
-      }
-      jr[i] = (xs + xs1) * rd[i];
-      bc[i] = (bs + bs1) * rd[i];
-      const T yi = rdlane(acc, i) * rd[i];
-      if (lane == i) yv = yi;
-      acc -= a[i] * yi;
-    }
-    // x0 = L^-T y ; c_k = ce0_k + B[:,k] . y ; trace(J0)
-    T x0 = 0, c2 = 0, ck = 0;
-#pragma unroll
-    for (int i = 0; i < NV; i++) {
-      const T yi = rdlane(yv, i);
-      x0 += jr[i] * yi;
-      ck += bc[i] * yi;
-      c2 += rdlane(jr[i], i);
-    }
-    c2 += T(c.nslot) * m.Jf0_trace;
-    if (lane < 6) ck += L.h[lane];
-    else if (lane < p) ck -= L.k.arhs[c.slot_foot[(lane - 6) / 6]][(lane - 6) % 6];
-    // force rows: J0 row of the constant block; B rows 26.. = L_f^-1 (-Jc)^T for the base-dynamics columns
-#pragma unroll
-    for (int j = NV; j < NVAR; j++) { jr[j] = 0; bc[j] = 0; }
-    if (lane >= NV && lane < n) {
-#pragma unroll
-      for (int i = 0; i < NV; i++) jr[i] = 0;
-      const int e = (lane - NV) % 12, sl = (lane - NV) / 12;
-#pragma unroll
-      for (int s2 = 0; s2 < 2; s2++)
-#pragma unroll
-        for (int b = 0; b < 12; b++)
-          if (s2 == sl && b >= e) jr[NV + 12 * s2 + b] = m.Jf0[e][b];
-    }
-    if (lane >= n) {
-#pragma unroll
-      for (int i = 0; i < NV; i++) jr[i] = 0;
-    }
-    if (lane < 6) {
-      for (int s2 = 0; s2 < c.nslot; s2++) {
-        T ce[12];
-#pragma unroll
-        for (int b = 0; b < 12; b++) ce[b] = L.Dyn[lane * LDD + NV + 12 * s2 + b];
-#pragma unroll
-        for (int e = 0; e < 12; e++) {
-          T sacc = 0;
-#pragma unroll
-          for (int b = 0; b <= e; b++) sacc += m.Jf0[b][e] * ce[b];
-#pragma unroll
-          for (int s3 = 0; s3 < 2; s3++)
-            if (s3 == s2) bc[NV + 12 * s3 + e] = sacc;
-        }
-      }
-    }
-    TSIDB_STAMP(5);
-    // ---- Householder QR of B (columns in lanes 0..p-1) applied to J (rows in lanes 0..n-1)
-    T R_norm = 1;
-    bool degenerate = false;
-#pragma unroll
-    for (int k = 0; k < 18; k++) {
-      if (k < p) {
-        // lane k owns column k: alpha, tail norm, reflector scale
-        T sig = 0;
-#pragma unroll
-        for (int i = k + 1; i < NVAR; i++) sig += bc[i] * bc[i];
-        const T alpha = rdlane(bc[k], k), sigma = rdlane(sig, k);
-        T dkk = alpha;
-        if (sigma > 0) {
-          const T nrm = sqrt(alpha * alpha + sigma);
-          const T v0 = alpha + (alpha >= 0 ? nrm : -nrm);
-          const T beta = T(2) / (v0 * v0 + sigma);
-          dkk = alpha >= 0 ? -nrm : nrm;
-          // s = v . b_col (lanes > k), w = J_row . v (all lanes)
-          T sb = v0 * bc[k], wj = v0 * jr[k], sb1 = 0, wj1 = 0;
-#pragma unroll
-          for (int i = k + 1; i < NVAR; i++) {
-            const T vi = rdlane(bc[i], k);
-            if (i & 1) { sb1 += vi * bc[i]; wj1 += vi * jr[i]; }
-            else { sb += vi * bc[i]; wj += vi * jr[i]; }
-          }
-          sb = (sb + sb1) * beta; wj = (wj + wj1) * beta;
-          const bool upd = lane > k; // columns <= k are final (their rows >= k are already zero)
-          jr[k] -= wj * v0;
-          if (upd) bc[k] -= sb * v0;
-#pragma unroll
-          for (int i = k + 1; i < NVAR; i++) {
-            const T vi = rdlane(bc[i], k); // lane k's column is untouched until the loop ends
-            jr[i] -= wj * vi;
-            if (upd) bc[i] -= sb * vi;
-          }
-          if (lane == k) {
-            bc[k] = dkk;
-#pragma unroll
-            for (int i = k + 1; i < NVAR; i++) bc[i] = 0;
-          }
-        }
-        const T ad = fabs(dkk);
-        if (ad <= Eps<T>::v * R_norm) degenerate = true;
-        if (ad > R_norm) R_norm = ad;
-      }
-    }
-    // ---- R^T t = -c (forward), x = x0 + J[:, :p] t  (the equality multipliers u = R^-1 t are not needed)
-    T tacc = -ck, tv[18];
-#pragma unroll
-    for (int i = 0; i < 18; i++) {
-      tv[i] = 0;
-      if (i < p) {
-        tv[i] = rdlane(tacc, i) / rdlane(bc[i], i);
-        tacc -= bc[i] * tv[i];
-      }
-    }
-    T xeq = lane < NV ? x0 : T(0);
-#pragma unroll
-    for (int k = 0; k < 18; k++) xeq += jr[k] * tv[k];
-    TSIDB_STAMP(6);
-    // ---- first feasibility sweep straight from registers' result; J / R go to LDS only if the
-    //      active-set iterations are actually needed
-    if (lane < n) L.x[lane] = xeq;
-    __syncthreads();
-    c.iq = p;
-    c.R_norm = R_norm;
-    int iters = 1;
-    int status = -1;
-    if (!spd) status = 2;
-    else if (degenerate) { status = 4; iters = 0; }
-    RowDesc<T> rdesc[3];
-#pragma unroll
-    for (int rr = 0; rr < 3; rr++) rdesc[rr] = row_desc(m, L, c, lane + WAVE * rr);
-    if (status < 0) {
-      act_partials(L, n, lane);
-      __syncthreads();
-      T psi = 0;
-#pragma unroll
-      for (int rr = 0; rr < 3; rr++)
-        if (lane + WAVE * rr < c.nin) {
-          const T sv = row_eval(rdesc[rr], L);
-          psi += sv < 0 ? sv : T(0);
-        }
-      psi = wave_sum(psi);
-      if (fabs(psi) <= T(c.nin) * T(2.220446049250313e-16) * c1 * c2 * T(100)) status = 0;
-    }
-    if (status < 0) status = qp_active_regs(m, L, c, lane, jr, xeq, rdesc, c1, c2, (int)m.params[P_MAX_ITER], iters);
-    qp_status = status;
-    qp_iters = iters;
-  }
+  tick_qp<T, NS>(m, L, c, lane, a, rd, gi, c1, spd, qp_status, qp_iters);
   int status = qp_status, iters = qp_iters;
 
   TSIDB_STAMP(8);
