@@ -42,6 +42,8 @@ for nm, ix in zip(names_t, idx_t):
 print(f"  {'total':24s} {tot:10.0f} cyc")
 for nm, k in (("  as: sweep (row values)", 10), ("  as: select+np", 11), ("  as: d = J^T np", 12), ("  as: householder+z", 13), ("  as: r, steps, add", 14)):
     print(f"{nm:26s} {np.median(b[:, k]):10.0f} cyc (sum over iterations)")
+for nm, k in (("  rbd: setup+sincos", 15), ("  rbd: depth loop", 23), ("  rbd: inertia+force", 29), ("  rbd: subtree gather", 30), ("  rbd: per-dof h,M", 31)):
+    print(f"{nm:26s} {np.median(b[:, k]):10.0f} cyc")
 names_s = ["kin+bias+M", "qacc_smooth chol", "collision", "rows+warmstart", "newton loop", "euler+write"]
 idx_s = [(16, 17), (17, 18), (18, 19), (19, 20), (20, 21), (21, 22)]
 tot = np.median(b[:, 22] - b[:, 16])
