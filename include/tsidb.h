@@ -57,6 +57,12 @@ int tsidb_set_params(tsidb_handle h, const double *params, int n_params);
 int tsidb_set_refs(tsidb_handle h, const void *com_ref, const void *posture_ref, const void *foot_ref,
                    const void *contact_ref, const uint8_t *contact_active, const void *cop_frames);
 
+/* per-env randomisation of the sim stage (BASELINE.json configs[4]; no reference counterpart):
+ * env_params [N,8] in the path's arithmetic type = mass scale applied to every sim body's mass and inertia,
+ * contact friction, unit floor normal (3), floor offset d (plane n.x = d), 2 spare.  NULL = nominal
+ * model (floor z = 0, friction 1).  The pointer is remembered, not copied. */
+int tsidb_set_env_params(tsidb_handle h, const void *env_params);
+
 /* reset: WalkController.py:22-26,72-79 (standing state, soles onto z = 0), the references of
  * :81,122,151-152,164-165, and main.py:57-64 (mj_data.qpos = q).  env_ids (device, int32) selects
  * envs; NULL = all.  Writes state AND the reference buffers registered with tsidb_set_refs. */

@@ -7,11 +7,11 @@
 #include <omp.h>
 #endif
 
-int or_env_step_batch(const OrModel *m, const double *params, int n, double *q, double *v, double *qpos,
-                      double *qvel, double *qacc_ws, const double *com_ref, const double *posture_ref,
-                      const double *foot_ref, const double *contact_ref, const uint8_t *contact_active,
-                      const double *cop_frames, double *tau, double *dv, double *f, int32_t *status,
-                      double *obs, int32_t *ncon, int32_t *con_geom, int nthreads) {
+int or_env_step_batch_env(const OrModel *m, const double *params, int n, double *q, double *v, double *qpos,
+                          double *qvel, double *qacc_ws, const double *com_ref, const double *posture_ref,
+                          const double *foot_ref, const double *contact_ref, const uint8_t *contact_active,
+                          const double *cop_frames, const double *env_params, double *tau, double *dv, double *f,
+                          int32_t *status, double *obs, int32_t *ncon, int32_t *con_geom, int nthreads) {
   const int sim = params[P_SIM_ENABLED] != 0.0;
   const int quirks = params[P_QUIRKS] != 0.0;
 #ifdef _OPENMP
@@ -35,7 +35,7 @@ int or_env_step_batch(const OrModel *m, const double *params, int n, double *q, 
     /* main.py:193-194  ctrl = map_tsid_to_mujoco(q) */
     for (int a = 0; a < OR_NA; a++) ctrl[a] = qe[m->mj_ctrl_qidx[a]];
     OrSimInfo info;
-    int rc = or_sim_step(m, qp, qv, ctrl, qacc_ws + (size_t)e * OR_NV, &info);
+    int rc = or_sim_step_env(m, qp, qv, ctrl, qacc_ws + (size_t)e * OR_NV, env_params ? env_params + (size_t)e * 8 : NULL, &info);
     if (rc) status[e] |= 0x100;
     if (ncon) ncon[e] = info.ncon;
     if (con_geom) {
@@ -44,4 +44,13 @@ int or_env_step_batch(const OrModel *m, const double *params, int n, double *q, 
     }
   }
   return 0;
+}
+
+int or_env_step_batch(const OrModel *m, const double *params, int n, double *q, double *v, double *qpos,
+                      double *qvel, double *qacc_ws, const double *com_ref, const double *posture_ref,
+                      const double *foot_ref, const double *contact_ref, const uint8_t *contact_active,
+                      const double *cop_frames, double *tau, double *dv, double *f, int32_t *status,
+                      double *obs, int32_t *ncon, int32_t *con_geom, int nthreads) {
+  return or_env_step_batch_env(m, params, n, q, v, qpos, qvel, qacc_ws, com_ref, posture_ref, foot_ref, contact_ref,
+                               contact_active, cop_frames, NULL, tau, dv, f, status, obs, ncon, con_geom, nthreads);
 }

@@ -151,8 +151,12 @@ static void ls_eval(const Efc *e, const double *jar, const double *Jv, const dou
   *cost = c; *d1 = g; *d2 = h;
 }
 
-int or_sim_step(const OrModel *m, double *qpos, double *qvel, const double *ctrl, double *qacc_ws,
-                OrSimInfo *info) {
+/* envp (may be NULL = nominal): per-env randomisation of BASELINE config 5 -
+ * [0] mass scale (every sim body's mass and inertia), [1] contact friction, [2..4] unit floor normal,
+ * [5] floor offset d (plane n.x = d).  Compile-time constants derived at qpos0 (inverse weights, kv,
+ * meaninertia) stay nominal, as when body_mass is edited in a compiled MuJoCo model. */
+int or_sim_step_env(const OrModel *m, double *qpos, double *qvel, const double *ctrl, double *qacc_ws,
+                    const double *envp, OrSimInfo *info) {
   const double dt = m->opt[0], gz = m->opt[1], tol = m->opt[2];
   const int maxiter = (int)m->opt[3], ls_iter = (int)m->opt[4];
   const double ls_tol = m->opt[5];
@@ -195,8 +199,9 @@ int or_sim_step(const OrModel *m, double *qpos, double *qvel, const double *ctrl
   WInertia Y[NB], Yc[NB];
   for (int b = 0; b < NB; b++) {
     const double *in = m->mj_inertia[b];
-    double I[9] = {in[4], in[5], in[6], in[5], in[7], in[8], in[6], in[8], in[9]}, T[9], RT[9];
-    Y[b].m = in[0];
+    const double ms = envp ? envp[0] : 1.0;
+    double I[9] = {ms * in[4], ms * in[5], ms * in[6], ms * in[5], ms * in[7], ms * in[8], ms * in[6], ms * in[8], ms * in[9]}, T[9], RT[9];
+    Y[b].m = ms * in[0];
     matvec(Rb[b], in + 1, Y[b].c);
     for (int i = 0; i < 3; i++) Y[b].c[i] += pb[b][i];
     matmul3(Rb[b], I, T);
@@ -274,24 +279,41 @@ int or_sim_step(const OrModel *m, double *qpos, double *qvel, const double *ctrl
   chol_solve(L, NV, qfrc_smooth, info->qacc_smooth);
 
   /* ---------------- collision: floor plane (z = 0, normal +z) vs every body's hull */
-  const double nrm[3] = {0, 0, 1}, t1[3] = {0, 1, 0}, t2[3] = {-1, 0, 0}; /* mju_makeFrame for +z */
+  /* floor plane n.x = d and its contact frame (mju_makeFrame: t1 from y unless |n_y| >= 0.5, t2 = n x t1) */
+  double nrm[3] = {0, 0, 1}, t1[3], t2[3], pd = 0.0;
+  if (envp) { nrm[0] = envp[2]; nrm[1] = envp[3]; nrm[2] = envp[4]; pd = envp[5]; }
+  {
+    double t[3] = {0, 0, 0};
+    if (fabs(nrm[1]) < 0.5) t[1] = 1; else t[2] = 1;
+    double dn = dot3(nrm, t), nn = 0;
+    for (int i = 0; i < 3; i++) { t1[i] = t[i] - dn * nrm[i]; nn += t1[i] * t1[i]; }
+    nn = 1.0 / sqrt(nn);
+    for (int i = 0; i < 3; i++) t1[i] *= nn;
+    cross(nrm, t1, t2);
+  }
   const double margin = 0.0;
   int ncon = 0;
   for (int b = 0; b < NB && ncon < OR_MAXCON; b++) {
     double cw[3];
     matvec(Rb[b], m->rbound[b], cw);
-    if (cw[2] + pb[b][2] - m->rbound[b][3] > margin) continue;
+    for (int i = 0; i < 3; i++) cw[i] += pb[b][i];
+    if (dot3(nrm, cw) - pd - m->rbound[b][3] > margin) continue;
+    /* floor normal in the body frame, plane offset seen from the body origin */
+    const double rn[3] = {nrm[0] * Rb[b][0] + nrm[1] * Rb[b][3] + nrm[2] * Rb[b][6],
+                          nrm[0] * Rb[b][1] + nrm[1] * Rb[b][4] + nrm[2] * Rb[b][7],
+                          nrm[0] * Rb[b][2] + nrm[1] * Rb[b][5] + nrm[2] * Rb[b][8]};
+    const double pz = dot3(nrm, pb[b]) - pd;
     int v0 = m->hull_adr[b], v1 = m->hull_adr[b + 1];
     double zmin = INFINITY;
     for (int i = v0; i < v1; i++) {
       const double *v = m->hull_vert + 3 * i;
-      double z = Rb[b][6] * v[0] + Rb[b][7] * v[1] + Rb[b][8] * v[2] + pb[b][2];
+      double z = rn[0] * v[0] + rn[1] * v[1] + rn[2] * v[2] + pz;
       if (z < zmin) zmin = z;
     }
     int best = -1;
     for (int i = v0; i < v1 && best < 0; i++) {
       const double *v = m->hull_vert + 3 * i;
-      double z = Rb[b][6] * v[0] + Rb[b][7] * v[1] + Rb[b][8] * v[2] + pb[b][2];
+      double z = rn[0] * v[0] + rn[1] * v[1] + rn[2] * v[2] + pz;
       if (z <= zmin + TIE_TOL) best = i;
     }
     if (zmin > margin) continue;
@@ -304,7 +326,7 @@ int or_sim_step(const OrModel *m, double *qpos, double *qvel, const double *ctrl
       double w[3];
       matvec(Rb[b], v, w);
       for (int i = 0; i < 3; i++) w[i] += pb[b][i];
-      double dist = w[2];
+      double dist = dot3(nrm, w) - pd;
       if (c > 0 && dist > margin) continue;
       info->con_geom[ncon] = b;
       info->con_vert[ncon] = cand[c] - v0;
@@ -318,7 +340,7 @@ int or_sim_step(const OrModel *m, double *qpos, double *qvel, const double *ctrl
   /* ---------------- constraint rows: frictionloss dofs, then pyramidal contact rows */
   static __thread Efc e;
   e.nefc = 0;
-  const double mu = m->contact[0];
+  const double mu = envp ? envp[1] : m->contact[0];
   const double timeconst = m->contact[1] > 2 * dt ? m->contact[1] : 2 * dt, dampratio = m->contact[2];
   const double dmin = m->contact[3], dmax = m->contact[4], width = m->contact[5], mid = m->contact[6], power = m->contact[7];
   const double kk = 1.0 / (dmax * dmax * timeconst * timeconst * dampratio * dampratio), bb = 2.0 / (dmax * timeconst);
@@ -504,4 +526,9 @@ int or_sim_step(const OrModel *m, double *qpos, double *qvel, const double *ctrl
   }
   for (int k = 6; k < NV; k++) qpos[k + 1] += dt * qvel[k];
   return 0;
+}
+
+int or_sim_step(const OrModel *m, double *qpos, double *qvel, const double *ctrl, double *qacc_ws,
+                OrSimInfo *info) {
+  return or_sim_step_env(m, qpos, qvel, ctrl, qacc_ws, NULL, info);
 }

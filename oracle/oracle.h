@@ -116,6 +116,9 @@ typedef struct {
 } OrSimInfo;
 int or_sim_step(const OrModel *m, double *qpos, double *qvel, const double *ctrl, double *qacc_ws,
                 OrSimInfo *info);
+/* same with the per-env randomisation of BASELINE config 5: envp = mass scale, friction, floor normal (3), offset */
+int or_sim_step_env(const OrModel *m, double *qpos, double *qvel, const double *ctrl, double *qacc_ws,
+                    const double *envp, OrSimInfo *info);
 
 /* whole env step (tick + base teleport + ctrl map + sim step): main.py:119-129,192-195 */
 int or_env_step_batch(const OrModel *m, const double *params, int n, double *q, double *v, double *qpos,
@@ -123,6 +126,12 @@ int or_env_step_batch(const OrModel *m, const double *params, int n, double *q, 
                       const double *foot_ref, const double *contact_ref, const uint8_t *contact_active,
                       const double *cop_frames, double *tau, double *dv, double *f, int32_t *status,
                       double *obs, int32_t *ncon, int32_t *con_geom, int nthreads);
+int or_env_step_batch_env(const OrModel *m, const double *params, int n, double *q, double *v, double *qpos,
+                          double *qvel, double *qacc_ws, const double *com_ref, const double *posture_ref,
+                          const double *foot_ref, const double *contact_ref, const uint8_t *contact_active,
+                          const double *cop_frames, const double *env_params /* [n][8] or NULL */, double *tau,
+                          double *dv, double *f, int32_t *status, double *obs, int32_t *ncon, int32_t *con_geom,
+                          int nthreads);
 
 #ifdef __cplusplus
 }

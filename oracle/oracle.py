@@ -66,7 +66,7 @@ class Oracle:
         L.or_model_load.argtypes = [C.c_char_p, C.c_size_t]
         for name in ("or_model_free", "or_rbd_terms", "or_rnea", "or_integrate", "or_log6", "or_tsid_assemble"):
             getattr(L, name).restype = None
-        for name in ("or_qp_solve", "or_tsid_tick", "or_sim_step", "or_env_step_batch"):
+        for name in ("or_qp_solve", "or_tsid_tick", "or_sim_step", "or_sim_step_env", "or_env_step_batch", "or_env_step_batch_env"):
             getattr(L, name).restype = C.c_int
         self.m = C.c_void_p(L.or_model_load(blob_bytes, len(blob_bytes)))
         if not self.m:
@@ -141,11 +141,13 @@ class Oracle:
         return dict(tau=tau, dv=dv, f=f, obs=obs, status=st, iters=it.value)
 
     # ---- sim
-    def sim_step(self, qpos, qvel, ctrl, qacc_ws):
+    def sim_step(self, qpos, qvel, ctrl, qacc_ws, envp=None):
         assert all(x.dtype == np.float64 for x in (qpos, qvel, qacc_ws))
         ctrl = _f64(ctrl)
         info = OrSimInfo()
-        rc = self.lib.or_sim_step(self.m, _p(qpos), _p(qvel), _p(ctrl), _p(qacc_ws), C.byref(info))
+        ep = _f64(envp) if envp is not None else None
+        rc = self.lib.or_sim_step_env(self.m, _p(qpos), _p(qvel), _p(ctrl), _p(qacc_ws), _p(ep) if ep is not None else None,
+                                      C.byref(info))
         nc, ne = info.ncon, info.nefc
         return dict(rc=rc, ncon=nc, nefc=ne, iters=info.solver_iter, con_geom=np.array(info.con_geom)[:nc],
                     con_vert=np.array(info.con_vert)[:nc], con_dist=np.array(info.con_dist)[:nc],
@@ -159,10 +161,12 @@ class Oracle:
         n = st["q"].shape[0]
         params = _f64(params)
         cf = st.get("cop_frames")
-        self.lib.or_env_step_batch(
+        ep = st.get("env_params")
+        self.lib.or_env_step_batch_env(
             self.m, _p(params), n, _p(st["q"]), _p(st["v"]), _p(st["qpos"]), _p(st["qvel"]), _p(st["qacc_ws"]),
             _p(st["com_ref"]), _p(st["posture_ref"]), _p(st["foot_ref"]), _p(st["contact_ref"]),
-            _p(st["contact_active"]), _p(cf) if cf is not None else None, _p(st["tau"]), _p(st["dv"]), _p(st["f"]),
+            _p(st["contact_active"]), _p(cf) if cf is not None else None, _p(ep) if ep is not None else None,
+            _p(st["tau"]), _p(st["dv"]), _p(st["f"]),
             _p(st["status"]), _p(st["obs"]), _p(st["ncon"]), _p(st["con_geom"]), int(nthreads))
 
 

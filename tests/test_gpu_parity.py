@@ -301,6 +301,39 @@ def test_infeasible_envs_are_flagged_not_fatal(oracle):
     assert wc.status.cpu().numpy().tolist() == [0] * 6
 
 
+def test_randomised_envs_config5_f64(oracle):
+    """BASELINE config 5 in small: per-env mass scale, contact friction and tilted floor (contact-solver
+    stress); sim driven by the TSID loop for 40 steps, plus a settle run without the teleport."""
+    n = 32
+    wc = make(n)
+    perturb(wc, 13)
+    wc.randomize(seed=2)
+    st = mirror(wc)
+    st["env_params"] = wc.env_params.cpu().numpy().copy()
+    for i in range(40):
+        wc.step()
+        oracle.env_step_batch(wc.params, st, nthreads=8)
+        assert np.array_equal(wc.ncon.cpu().numpy(), st["ncon"]), i
+        assert np.array_equal(wc.con_pairs.cpu().numpy(), st["con_geom"]), i
+        assert diff(wc.qpos, st["qpos"]) < 1e-9 and diff(wc.qvel, st["qvel"]) < 1e-6, i
+    assert int(wc.ncon.max()) > 0
+    # settle on the tilted floors without the teleport
+    wc2 = make(8)
+    wc2.randomize(seed=3, tilt_deg=5.0)
+    wc2.qpos[:, 3:7] = torch.tensor([1.0, 0, 0, 0], dtype=wc2.dtype, device=wc2.device)
+    wc2.qpos[:, 2] -= 0.002
+    ep = wc2.env_params.cpu().numpy()
+    qpos, qvel, ws = (x.cpu().numpy().copy() for x in (wc2.qpos, wc2.qvel, wc2.qacc_warmstart))
+    for i in range(150):
+        wc2.sim_step(teleport=False)
+        for e in range(8):
+            oracle.sim_step(qpos[e], qvel[e], np.zeros(20), ws[e], envp=ep[e])
+    assert diff(wc2.qpos, qpos) < 1e-7 and diff(wc2.qvel, qvel) < 1e-4
+    assert int(wc2.ncon.min()) >= 1
+    wc2.set_env_params()   # back to the nominal model
+    assert wc2.env_params is None
+
+
 def test_shard_invariance_bitwise():
     """1 vs 2 shards give bit-identical per-env results (what 1/2/4/8 GPUs must reproduce)."""
     full = make(32)

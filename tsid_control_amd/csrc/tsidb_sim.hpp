@@ -96,9 +96,16 @@ template <typename T> __device__ __forceinline__ T mulM(const SimLds<T> &L, cons
   return s;
 }
 
+// floor plane n.x = d with its contact frame (mju_makeFrame: t1 from y unless |n_y| >= 0.5, t2 = n x t1)
+template <typename T>
+struct Floor {
+  T n[3], t1[3], t2[3], d;
+};
+
 // the 4 pyramid rows of contact `c` applied to generalized vector x (LDS): J_row x
 template <typename T>
-__device__ __forceinline__ void contact_rows(const DevModel<T> &m, const SimLds<T> &L, int c, const T *x, T mu, T *out) {
+__device__ __forceinline__ void contact_rows(const DevModel<T> &m, const SimLds<T> &L, const Floor<T> &fl, int c, const T *x,
+                                             T mu, T *out) {
   T tw[6] = {0, 0, 0, 0, 0, 0};
   for (unsigned mk = L.anc[L.cbody[c]]; mk; mk &= mk - 1) {
     const int a = __ffs(mk) - 1;
@@ -117,8 +124,8 @@ __device__ __forceinline__ void contact_rows(const DevModel<T> &m, const SimLds<
   }
   T wxr[3];
   cross3(tw + 3, L.cr[c], wxr);
-  // contact frame for the +z floor normal (mju_makeFrame): n = z, t1 = y, t2 = -x
-  const T un = tw[2] + wxr[2], u1 = tw[1] + wxr[1], u2 = -(tw[0] + wxr[0]);
+  const T u[3] = {tw[0] + wxr[0], tw[1] + wxr[1], tw[2] + wxr[2]};
+  const T un = dot3(fl.n, u), u1 = dot3(fl.t1, u), u2 = dot3(fl.t2, u);
   out[0] = un + mu * u1; out[1] = un - mu * u1; out[2] = un + mu * u2; out[3] = un - mu * u2;
 }
 
@@ -154,7 +161,24 @@ __device__ __forceinline__ void rows_eval(const RowState<T> &rs, T alpha, T &c, 
 
 template <typename T>
 __device__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L, int lane, const T *q_tsid, T *qpos_g, T *qvel_g,
-                             T *qacc_ws_g, T *qacc_out, int *ncon_out, int *con_out, int *info) {
+                             T *qacc_ws_g, const T *envp, T *qacc_out, int *ncon_out, int *con_out, int *info) {
+  // per-env randomisation (BASELINE config 5), NULL = nominal: mass scale, contact friction, floor plane
+  const T mscale = envp ? envp[0] : T(1);
+  Floor<T> fl;
+  fl.n[0] = envp ? envp[2] : T(0); fl.n[1] = envp ? envp[3] : T(0); fl.n[2] = envp ? envp[4] : T(1);
+  fl.d = envp ? envp[5] : T(0);
+  {
+    T t[3] = {0, 0, 0};
+    if (fabs(fl.n[1]) < T(0.5)) t[1] = 1; else t[2] = 1;
+    const T dn = dot3(fl.n, t);
+    T nn = 0;
+#pragma unroll
+    for (int i = 0; i < 3; i++) { fl.t1[i] = t[i] - dn * fl.n[i]; nn += fl.t1[i] * fl.t1[i]; }
+    nn = T(1) / sqrt(nn);
+#pragma unroll
+    for (int i = 0; i < 3; i++) fl.t1[i] *= nn;
+    cross3(fl.n, fl.t1, fl.t2);
+  }
   const T dt = m.opt[0], gz = m.opt[1], tol = m.opt[2];
   const int maxiter = (int)m.opt[3], ls_iter = (int)m.opt[4];
   const T ls_tol = m.opt[5];
@@ -260,7 +284,8 @@ __device__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L, int lane, const
   if (lane < NB) {
     const int b = lane;
     const T *Yb = m.mj_inertia[b];
-    T cw[3], I[9] = {Yb[4], Yb[5], Yb[6], Yb[5], Yb[7], Yb[8], Yb[6], Yb[8], Yb[9]}, Tm[9], RT[9];
+    T cw[3], I[9] = {mscale * Yb[4], mscale * Yb[5], mscale * Yb[6], mscale * Yb[5], mscale * Yb[7], mscale * Yb[8],
+                     mscale * Yb[6], mscale * Yb[8], mscale * Yb[9]}, Tm[9], RT[9];
     mat3vec(Rb, Yb + 1, cw);
 #pragma unroll
     for (int i = 0; i < 3; i++) cw[i] += pb[i];
@@ -270,7 +295,7 @@ __device__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L, int lane, const
 #pragma unroll
       for (int k = 0; k < 3; k++) RT[3 * i + k] = Rb[3 * k + i];
     mat3mul(Tm, RT, I);
-    const T mass = Yb[0], c2 = dot3(cw, cw);
+    const T mass = mscale * Yb[0], c2 = dot3(cw, cw);
     T Y[10];
     Y[0] = mass; Y[1] = mass * cw[0]; Y[2] = mass * cw[1]; Y[3] = mass * cw[2];
     Y[4] = I[0] + mass * (c2 - cw[0] * cw[0]); Y[5] = I[1] - mass * cw[0] * cw[1]; Y[6] = I[2] - mass * cw[0] * cw[2];
@@ -353,16 +378,21 @@ __device__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L, int lane, const
   if (lane < NV) L.qas[lane] = qas;
 
   TSIDB_STAMP(18);
-  // ---- collision: floor plane (z = 0, normal +z) against each body's convex hull
+  // ---- collision: floor plane (n.x = d; nominal z = 0) against each body's convex hull
   const T margin = 0, tie_tol = m.opt[6];
+  const T Ow[3] = {L.qpos[0], L.qpos[1], L.qpos[2]};
+  const T nO = dot3(fl.n, Ow) - fl.d; // signed distance of the base origin O to the floor
   int ncon = 0;
   for (int b = 0; b < NB && ncon < MAXCON; b++) {
     const T *Rb = L.R[b];
-    const T pz = L.p[b][2] + Oz;
-    const T zc = Rb[6] * m.rbound[b][0] + Rb[7] * m.rbound[b][1] + Rb[8] * m.rbound[b][2] + pz;
+    // floor normal in the body frame; "z" below = signed distance to the floor
+    const T r6 = fl.n[0] * Rb[0] + fl.n[1] * Rb[3] + fl.n[2] * Rb[6];
+    const T r7 = fl.n[0] * Rb[1] + fl.n[1] * Rb[4] + fl.n[2] * Rb[7];
+    const T r8 = fl.n[0] * Rb[2] + fl.n[1] * Rb[5] + fl.n[2] * Rb[8];
+    const T pz = dot3(fl.n, L.p[b]) + nO;
+    const T zc = r6 * m.rbound[b][0] + r7 * m.rbound[b][1] + r8 * m.rbound[b][2] + pz;
     if (zc - m.rbound[b][3] > margin) continue;
     const int v0 = m.hull_adr[b], v1 = m.hull_adr[b + 1];
-    const T r6 = Rb[6], r7 = Rb[7], r8 = Rb[8];
     // exact pruned support search: the hull's vertices are stored in k-d order, 64 per chunk, each
     // chunk with a bounding box.  A chunk can hold the lowest vertex (or one within the tie
     // tolerance of it) only if the box's lower bound along the floor normal does not exceed the best
@@ -414,23 +444,25 @@ __device__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L, int lane, const
     int nnb = m.hull_eadr[best + 1] - e0;
     nnb = nnb > WAVE - 1 ? WAVE - 1 : nnb;
     bool keep = false;
-    T w[3] = {0, 0, 0};
+    T w[3] = {0, 0, 0}, wd = 0;
     int vid = best;
     if (lane <= nnb) {
       if (lane > 0) vid = v0 + m.hull_edge[e0 + lane - 1];
       const T vv[3] = {m.hull_x[vid], m.hull_y[vid], m.hull_z[vid]};
       mat3vec(Rb, vv, w);
-      w[0] += L.p[b][0]; w[1] += L.p[b][1]; w[2] += pz;
-      keep = lane == 0 || w[2] <= margin;
+      w[0] += L.p[b][0]; w[1] += L.p[b][1]; w[2] += L.p[b][2]; // relative to O
+      wd = dot3(fl.n, w) + nO;
+      keep = lane == 0 || wd <= margin;
     }
     const unsigned long long mask = __ballot(keep);
     const int slot = ncon + __popcll(mask & ((1ull << lane) - 1ull));
     if (keep && slot < MAXCON) {
-      const T dist = w[2];
+      const T dist = wd;
       L.cbody[slot] = b;
       L.cvert[slot] = vid - v0;
       L.cdist[slot] = dist;
-      L.cr[slot][0] = w[0]; L.cr[slot][1] = w[1]; L.cr[slot][2] = w[2] - T(0.5) * dist - Oz;
+#pragma unroll
+      for (int i = 0; i < 3; i++) L.cr[slot][i] = w[i] - T(0.5) * dist * fl.n[i];
     }
     ncon += __popcll(mask);
     ncon = ncon > MAXCON ? MAXCON : ncon;
@@ -441,7 +473,7 @@ __device__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L, int lane, const
 
   TSIDB_STAMP(19);
   // ---- constraint rows: frictionloss (lane = dof), pyramidal contact rows (lane = contact)
-  const T mu = m.contact[0];
+  const T mu = envp ? envp[1] : m.contact[0];
   const T timeconst = m.contact[1] > 2 * dt ? m.contact[1] : 2 * dt, dampratio = m.contact[2];
   const T dmin = m.contact[3], dmax = m.contact[4], width = m.contact[5], mid = m.contact[6], power = m.contact[7];
   const T kk = T(1) / (dmax * dmax * timeconst * timeconst * dampratio * dampratio), bb = T(2) / (dmax * timeconst);
@@ -477,7 +509,7 @@ __device__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L, int lane, const
     R0 = R0 > MINVAL ? R0 : MINVAL;
     rs.cD = T(1) / (2 * mu * mu * R0);
     T vel[4];
-    contact_rows(m, L, c, L.qvel, mu, vel);
+    contact_rows(m, L, fl, c, L.qvel, mu, vel);
 #pragma unroll
     for (int i = 0; i < 4; i++) rs.caref[i] = -bb * vel[i] - kk * imp * (dist - margin);
   }
@@ -492,7 +524,7 @@ __device__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L, int lane, const
       if (rs.has_f) rs.fjar = xa - rs.faref;
       if (rs.has_c) {
         T o[4];
-        contact_rows(m, L, lane, L.xv, mu, o);
+        contact_rows(m, L, fl, lane, L.xv, mu, o);
 #pragma unroll
         for (int i = 0; i < 4; i++) rs.cjar[i] = o[i] - rs.caref[i];
       }
@@ -543,9 +575,10 @@ __device__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L, int lane, const
         for (int i = 0; i < 4; i++) {
           const bool act = rs.cjar[i] < 0;
           fr[i] = act ? -rs.cD * rs.cjar[i] : T(0);
-          // direction of row i in world axes: n + s*mu*t, n = z, t1 = y, t2 = -x
+          // direction of row i in world axes: n + s*mu*t_k
           const T sg = (i & 1) ? -mu : mu;
-          const T dir[3] = {i >= 2 ? -sg : T(0), i < 2 ? sg : T(0), T(1)};
+          const T *tk = i < 2 ? fl.t1 : fl.t2;
+          const T dir[3] = {fl.n[0] + sg * tk[0], fl.n[1] + sg * tk[1], fl.n[2] + sg * tk[2]};
 #pragma unroll
           for (int e = 0; e < 3; e++) fv[e] += fr[i] * dir[e];
           if (act) {
@@ -662,7 +695,7 @@ __device__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L, int lane, const
       stage(search);
       const T Mv = mulM(L, L.xv, lane);
       if (rs.has_f) rs.fJv = search;
-      if (rs.has_c) contact_rows(m, L, lane, L.xv, mu, rs.cJv);
+      if (rs.has_c) contact_rows(m, L, fl, lane, L.xv, mu, rs.cJv);
       T qg1 = wave_sum(lane < NV ? search * (Ma - qfs) : T(0));
       T qg2 = wave_sum(lane < NV ? T(0.5) * search * Mv : T(0));
       T snorm = sqrt(wave_sum(lane < NV ? search * search : T(0)));

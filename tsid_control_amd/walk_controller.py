@@ -72,6 +72,7 @@ class WalkController:
         self.obs, self.frames = z(N, NOBS), z(N, 2, 12)
         self.ncon, self.con_pairs = z(N, dt=torch.int32), z(N, MAXCON, dt=torch.int32)
         self.info = z(N, 4, dt=torch.int32)
+        self.env_params = None
         rc = L.tsidb_set_refs(self._h, _ptr(self.com_ref), _ptr(self.posture_ref), _ptr(self.foot_ref),
                               _ptr(self.contact_ref), _ptr(self.contact_active), _ptr(self.cop_frames))
         _lib.check(L, self._h, rc, "tsidb_set_refs")
@@ -111,6 +112,41 @@ class WalkController:
         self.params = pack_params(self.conf, self.model.effort_limit, self.model.velocity_limit)
         rc = self._L.tsidb_set_params(self._h, self.params.ctypes.data_as(C.c_void_p), P_COUNT)
         _lib.check(self._L, self._h, rc, "tsidb_set_params")
+
+    def set_env_params(self, mass_scale=None, friction=None, floor_normal=None, floor_offset=None):
+        """Per-env randomisation of the sim stage (BASELINE config 5; no reference counterpart): any
+        of mass_scale [N], friction [N], floor_normal [N,3] (normalised here), floor_offset [N].
+        Calling with no argument restores the nominal model."""
+        if mass_scale is None and friction is None and floor_normal is None and floor_offset is None:
+            self.env_params = None
+            rc = self._L.tsidb_set_env_params(self._h, None)
+        else:
+            N = self.num_envs
+            ep = torch.zeros(N, 8, dtype=self.dtype, device=self.device)
+            ep[:, 0], ep[:, 1], ep[:, 4] = 1.0, 1.0, 1.0
+            if mass_scale is not None:
+                ep[:, 0] = torch.as_tensor(mass_scale, dtype=self.dtype, device=self.device)
+            if friction is not None:
+                ep[:, 1] = torch.as_tensor(friction, dtype=self.dtype, device=self.device)
+            if floor_normal is not None:
+                nrm = torch.as_tensor(floor_normal, dtype=self.dtype, device=self.device).reshape(N, 3)
+                ep[:, 2:5] = nrm / nrm.norm(dim=1, keepdim=True)
+            if floor_offset is not None:
+                ep[:, 5] = torch.as_tensor(floor_offset, dtype=self.dtype, device=self.device)
+            self.env_params = ep
+            rc = self._L.tsidb_set_env_params(self._h, _ptr(ep))
+        _lib.check(self._L, self._h, rc, "tsidb_set_env_params")
+
+    def randomize(self, seed=2, mass=(0.8, 1.2), friction=(0.4, 1.0), tilt_deg=5.0):
+        """BASELINE config 5 workload: body-mass scale U(mass), contact friction
+        U(friction), floor = random plane through the origin tilted by at most tilt_deg."""
+        g = torch.Generator().manual_seed(seed)
+        N = self.num_envs
+        u = lambda lo, hi: lo + (hi - lo) * torch.rand(N, generator=g, dtype=torch.float64)
+        tilt = torch.deg2rad(u(0.0, tilt_deg))
+        az = u(0.0, 2 * np.pi)
+        nrm = torch.stack([torch.sin(tilt) * torch.cos(az), torch.sin(tilt) * torch.sin(az), torch.cos(tilt)], dim=1)
+        self.set_env_params(mass_scale=u(*mass), friction=u(*friction), floor_normal=nrm, floor_offset=torch.zeros(N, dtype=torch.float64))
 
     # ------------------------------------------------------------------ reset / step
     def reset(self, env_ids=None):
