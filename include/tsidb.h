@@ -33,7 +33,7 @@ enum {
   TSIDB_P_KD_COM, TSIDB_P_W_POSTURE, TSIDB_P_HESS_REG, TSIDB_P_QUIRKS, TSIDB_P_NORMAL /*3*/,
   TSIDB_P_CPOINTS = TSIDB_P_NORMAL + 3 /*4x3*/, TSIDB_P_KP_POSTURE = TSIDB_P_CPOINTS + 12 /*20*/,
   TSIDB_P_KD_POSTURE = TSIDB_P_KP_POSTURE + 20, TSIDB_P_TAU_MAX = TSIDB_P_KD_POSTURE + 20,
-  TSIDB_P_V_MAX = TSIDB_P_TAU_MAX + 20, TSIDB_P_MAX_ITER = TSIDB_P_V_MAX + 20, TSIDB_P_SIM_ENABLED,
+  TSIDB_P_V_MAX = TSIDB_P_TAU_MAX + 20, TSIDB_P_MAX_ITER = TSIDB_P_V_MAX + 20, TSIDB_P_SIM_ENABLED, TSIDB_P_CLOSED_LOOP,
   TSIDB_P_COUNT = 128
 };
 
@@ -83,7 +83,11 @@ int tsidb_tick(tsidb_handle h, void *q, void *v, void *tau, void *dv, void *f, i
 int tsidb_sim(tsidb_handle h, const void *q_tsid, void *qpos, void *qvel, void *qacc_ws, void *qacc,
               int32_t *ncon, int32_t *con_pairs, int32_t *info, void *stream);
 
-/* whole env step, n_substeps times: tsidb_tick then (if params[SIM_ENABLED]) tsidb_sim. */
+/* whole env step, n_substeps times: tsidb_tick then (if params[SIM_ENABLED]) tsidb_sim.
+ * With params[CLOSED_LOOP] (not in the reference, whose coupling is one-way, main.py:126-129,
+ * 192-195): each tick first reads the TSID state from the sim state (quat wxyz -> xyzw, world-frame base
+ * linear velocity -> body frame, sim joint order -> TSID order), and the sim stage applies tau as motor
+ * torques and keeps its own base pose instead of the teleport + position servos. */
 int tsidb_step(tsidb_handle h, void *q, void *v, void *qpos, void *qvel, void *qacc_ws, void *tau, void *dv,
                void *f, int32_t *status, void *obs, void *frames, int32_t *ncon, int32_t *con_pairs,
                int32_t *info, int n_substeps, void *stream);

@@ -2,10 +2,30 @@
  * One env step = main.py:119-129 (TSID tick) then main.py:192-195 (base teleport, ctrl map,
  * mj_step).  OpenMP over envs is used only by bench.py's cpu_baseline leg. */
 #include "oracle.h"
+#include <math.h>
 #include <string.h>
 #ifdef _OPENMP
 #include <omp.h>
 #endif
+
+/* closed loop: TSID state from the sim state.  qpos = p, quat wxyz, joints in sim
+ * order; qvel = world-frame linear velocity, body-frame angular velocity, joint rates.  TSID wants quat
+ * xyzw, body-frame linear velocity and its own joint order. */
+static void sim_to_tsid(const OrModel *m, const double *qpos, const double *qvel, double *q, double *v) {
+  for (int i = 0; i < 3; i++) q[i] = qpos[i];
+  q[3] = qpos[4]; q[4] = qpos[5]; q[5] = qpos[6]; q[6] = qpos[3];
+  double w = qpos[3], x = qpos[4], y = qpos[5], z = qpos[6], nn = 1.0 / sqrt(w * w + x * x + y * y + z * z);
+  w *= nn; x *= nn; y *= nn; z *= nn;
+  const double R[9] = {1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y),
+                       2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x),
+                       2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)};
+  for (int i = 0; i < 3; i++) v[i] = R[i] * qvel[0] + R[3 + i] * qvel[1] + R[6 + i] * qvel[2];
+  for (int i = 3; i < 6; i++) v[i] = qvel[i];
+  for (int a = 0; a < OR_NA; a++) {
+    q[m->mj_ctrl_qidx[a]] = qpos[7 + a];
+    v[m->mj_ctrl_qidx[a] - 1] = qvel[6 + a];
+  }
+}
 
 int or_env_step_batch_env(const OrModel *m, const double *params, int n, double *q, double *v, double *qpos,
                           double *qvel, double *qacc_ws, const double *com_ref, const double *posture_ref,
@@ -13,13 +33,15 @@ int or_env_step_batch_env(const OrModel *m, const double *params, int n, double 
                           const double *cop_frames, const double *env_params, double *tau, double *dv, double *f,
                           int32_t *status, double *obs, int32_t *ncon, int32_t *con_geom, int nthreads) {
   const int sim = params[P_SIM_ENABLED] != 0.0;
-  const int quirks = params[P_QUIRKS] != 0.0;
+  const int closed = params[P_CLOSED_LOOP] != 0.0;
+  const int quirks = params[P_QUIRKS] != 0.0 && !closed;
 #ifdef _OPENMP
   if (nthreads > 0) omp_set_num_threads(nthreads);
 #pragma omp parallel for schedule(dynamic, 4)
 #endif
   for (int e = 0; e < n; e++) {
     double *qe = q + (size_t)e * OR_NQ, *ve = v + (size_t)e * OR_NV;
+    if (closed) sim_to_tsid(m, qpos + (size_t)e * OR_NQ, qvel + (size_t)e * OR_NV, qe, ve);
     int st = or_tsid_tick(m, params, qe, ve, com_ref + (size_t)e * 9, posture_ref + (size_t)e * OR_NA,
                           foot_ref + (size_t)e * 48, contact_ref + (size_t)e * 24, contact_active + (size_t)e * 2,
                           cop_frames ? cop_frames + (size_t)e * 24 : NULL, tau + (size_t)e * OR_NA,
@@ -27,15 +49,18 @@ int or_env_step_batch_env(const OrModel *m, const double *params, int n, double 
     status[e] = st;
     if (!sim) continue;
     double *qp = qpos + (size_t)e * OR_NQ, *qv = qvel + (size_t)e * OR_NV;
-    double ctrl[OR_NA];
-    /* main.py:192  mj_data.qpos[:7] = q[:7]  (quirk F6a: xyzw copied into the wxyz slot) */
-    for (int i = 0; i < 3; i++) qp[i] = qe[i];
-    if (quirks) for (int i = 0; i < 4; i++) qp[3 + i] = qe[3 + i];
-    else { qp[3] = qe[6]; qp[4] = qe[3]; qp[5] = qe[4]; qp[6] = qe[5]; }
-    /* main.py:193-194  ctrl = map_tsid_to_mujoco(q) */
-    for (int a = 0; a < OR_NA; a++) ctrl[a] = qe[m->mj_ctrl_qidx[a]];
+    double ctrl[OR_NA] = {0};
+    if (!closed) {
+      /* main.py:192  mj_data.qpos[:7] = q[:7]  (quirk F6a: xyzw copied into the wxyz slot) */
+      for (int i = 0; i < 3; i++) qp[i] = qe[i];
+      if (quirks) for (int i = 0; i < 4; i++) qp[3 + i] = qe[3 + i];
+      else { qp[3] = qe[6]; qp[4] = qe[3]; qp[5] = qe[4]; qp[6] = qe[5]; }
+      /* main.py:193-194  ctrl = map_tsid_to_mujoco(q) */
+      for (int a = 0; a < OR_NA; a++) ctrl[a] = qe[m->mj_ctrl_qidx[a]];
+    }
     OrSimInfo info;
-    int rc = or_sim_step_env(m, qp, qv, ctrl, qacc_ws + (size_t)e * OR_NV, env_params ? env_params + (size_t)e * 8 : NULL, &info);
+    int rc = or_sim_step_full(m, qp, qv, ctrl, closed ? tau + (size_t)e * OR_NA : NULL, qacc_ws + (size_t)e * OR_NV,
+                              env_params ? env_params + (size_t)e * 8 : NULL, &info);
     if (rc) status[e] |= 0x100;
     if (ncon) ncon[e] = info.ncon;
     if (con_geom) {

@@ -157,6 +157,13 @@ static void ls_eval(const Efc *e, const double *jar, const double *Jv, const dou
  * meaninertia) stay nominal, as when body_mass is edited in a compiled MuJoCo model. */
 int or_sim_step_env(const OrModel *m, double *qpos, double *qvel, const double *ctrl, double *qacc_ws,
                     const double *envp, OrSimInfo *info) {
+  return or_sim_step_full(m, qpos, qvel, ctrl, NULL, qacc_ws, envp, info);
+}
+
+/* motor_tau (may be NULL): closed-loop mode - joint torques in TSID joint order applied as motor forces
+ * instead of the position servos */
+int or_sim_step_full(const OrModel *m, double *qpos, double *qvel, const double *ctrl, const double *motor_tau,
+                     double *qacc_ws, const double *envp, OrSimInfo *info) {
   const double dt = m->opt[0], gz = m->opt[1], tol = m->opt[2];
   const int maxiter = (int)m->opt[3], ls_iter = (int)m->opt[4];
   const double ls_tol = m->opt[5];
@@ -269,7 +276,8 @@ int or_sim_step_env(const OrModel *m, double *qpos, double *qvel, const double *
   memset(info->qfrc_actuator, 0, sizeof info->qfrc_actuator);
   for (int a = 0; a < OR_NA; a++) {
     int d = m->mj_act_dof[a];
-    info->qfrc_actuator[d] += m->mj_act_kp[a] * (ctrl[a] - qpos[d + 1]) - m->mj_act_kv[a] * qvel[d];
+    if (motor_tau) info->qfrc_actuator[d] += motor_tau[m->mj_ctrl_qidx[a] - 7];
+    else info->qfrc_actuator[d] += m->mj_act_kp[a] * (ctrl[a] - qpos[d + 1]) - m->mj_act_kv[a] * qvel[d];
   }
   double qfrc_smooth[NV];
   for (int k = 0; k < NV; k++) qfrc_smooth[k] = info->qfrc_actuator[k] - info->qfrc_bias[k];

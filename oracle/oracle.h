@@ -29,7 +29,7 @@ enum {
   P_HESS_REG, P_QUIRKS, P_NORMAL /*3*/, P_CPOINTS = P_NORMAL + 3 /*12*/,
   P_KP_POSTURE = P_CPOINTS + 12 /*20*/, P_KD_POSTURE = P_KP_POSTURE + 20,
   P_TAU_MAX = P_KD_POSTURE + 20, P_V_MAX = P_TAU_MAX + 20, P_MAX_ITER = P_V_MAX + 20,
-  P_SIM_ENABLED, P_COUNT = 128
+  P_SIM_ENABLED, P_CLOSED_LOOP, P_COUNT = 128
 };
 
 typedef struct {
@@ -119,6 +119,8 @@ int or_sim_step(const OrModel *m, double *qpos, double *qvel, const double *ctrl
 /* same with the per-env randomisation of BASELINE config 5: envp = mass scale, friction, floor normal (3), offset */
 int or_sim_step_env(const OrModel *m, double *qpos, double *qvel, const double *ctrl, double *qacc_ws,
                     const double *envp, OrSimInfo *info);
+int or_sim_step_full(const OrModel *m, double *qpos, double *qvel, const double *ctrl, const double *motor_tau,
+                     double *qacc_ws, const double *envp, OrSimInfo *info);
 
 /* whole env step (tick + base teleport + ctrl map + sim step): main.py:119-129,192-195 */
 int or_env_step_batch(const OrModel *m, const double *params, int n, double *q, double *v, double *qpos,

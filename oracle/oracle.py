@@ -58,7 +58,8 @@ def _f64(a):
 
 class Oracle:
     def __init__(self, blob_bytes: bytes, lib_path=None):
-        so = Path(lib_path) if lib_path else HERE / "liboracle.so"
+        import os
+        so = Path(lib_path or os.environ.get("TSIDB_ORACLE_LIB") or HERE / "liboracle.so")  # env: sanitizer build
         if not so.exists():
             so = build()
         self.lib = L = C.CDLL(str(so))

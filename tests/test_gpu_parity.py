@@ -334,6 +334,26 @@ def test_randomised_envs_config5_f64(oracle):
     assert wc2.env_params is None
 
 
+def test_closed_loop_matches_oracle_and_stands(oracle):
+    """TSID reads the sim state, the sim is driven by tau.  120 steps vs the oracle, and the
+    closed-loop robot keeps standing on its contacts."""
+    n = 16
+    wc = make(n, closed_loop=True)
+    assert float((wc.qpos[:, 3] - 1.0).abs().max()) == 0          # reset wrote a proper wxyz quaternion
+    g = torch.Generator().manual_seed(5)
+    wc.qpos[:, 7:] += ((torch.rand(n, 20, generator=g, dtype=torch.float64) - 0.5) * 0.02).to(wc.device)
+    st = mirror(wc)
+    for i in range(120):
+        wc.step()
+        oracle.env_step_batch(wc.params, st, nthreads=8)
+        assert np.array_equal(wc.status.cpu().numpy(), st["status"]), i
+        assert np.array_equal(wc.ncon.cpu().numpy(), st["ncon"]), i
+        assert diff(wc.tau, st["tau"]) < 1e-6 and diff(wc.qpos, st["qpos"]) < 1e-8 and diff(wc.qvel, st["qvel"]) < 1e-5, i
+    assert int(wc.status.abs().sum()) == 0 and int(wc.ncon.min()) >= 2
+    assert 0.325 < float(wc.qpos[:, 2].min()) and float(wc.qpos[:, 2].max()) < 0.335
+    assert float(wc.qvel.abs().max()) < 0.5
+
+
 def test_shard_invariance_bitwise():
     """1 vs 2 shards give bit-identical per-env results (what 1/2/4/8 GPUs must reproduce)."""
     full = make(32)

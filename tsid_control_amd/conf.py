@@ -86,5 +86,7 @@ class RobotConfig:
     dtype = "f64"              # arithmetic type of the HIP path: "f64" (reference precision) or "f32"
     reference_quirks = True    # reproduce SURVEY.md F6 (a), (e): quaternion slot copy, stale CoP frames
     sim_enabled = True         # run the MuJoCo-subset step (main.py:192-195) after each TSID tick
+    closed_loop = False        # TSID reads the sim state each tick and the sim is driven by tau
+    #                            (torque actuators) instead of the reference's teleport + position servos
     qp_max_iter = 1000         # eiquadprog-fast DEFAULT_MAX_ITER
     hessian_regularization = 1e-8  # tsid SolverHQuadProgFast default

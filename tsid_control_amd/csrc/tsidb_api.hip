@@ -18,7 +18,8 @@ template <typename T>
 __global__ __launch_bounds__(WAVE) void k_tick(const DevModel<T> *__restrict__ mp, int n, T *q, T *v, const T *com_ref,
                                                const T *posture_ref, const T *foot_ref, const T *contact_ref,
                                                const uint8_t *cact, const T *cop_frames, T *tau, T *dv, T *f,
-                                               int *status, T *obs, T *frames, int *info) {
+                                               int *status, T *obs, T *frames, int *info, const T *qpos_sim,
+                                               const T *qvel_sim) {
   __shared__ TickLds<T> L;
   const int e = blockIdx.x, lane = threadIdx.x;
   if (e >= n) return;
@@ -28,7 +29,8 @@ __global__ __launch_bounds__(WAVE) void k_tick(const DevModel<T> *__restrict__ m
 #define TSIDB_TICK_ARGS                                                                                                    \
   *mp, L, lane, q + E * NQ, v + E * NV, com_ref + E * 9, posture_ref + E * NA, foot_ref + E * 48, contact_ref + E * 24,  \
       cact + E * 2, cop_frames ? cop_frames + E * 24 : nullptr, tau + E * NA, dv + E * NV, f + E * 24, status + e,       \
-      obs ? obs + E * NOBS : nullptr, info ? info + E * 4 : nullptr
+      obs ? obs + E * NOBS : nullptr, info ? info + E * 4 : nullptr, qpos_sim ? qpos_sim + E * NQ : nullptr,    \
+      qvel_sim ? qvel_sim + E * NV : nullptr
   if (nslot == 2) tsid_tick_env<T, 2>(TSIDB_TICK_ARGS);
   else if (nslot == 1) tsid_tick_env<T, 1>(TSIDB_TICK_ARGS);
   else tsid_tick_env<T, 0>(TSIDB_TICK_ARGS);
@@ -38,13 +40,15 @@ __global__ __launch_bounds__(WAVE) void k_tick(const DevModel<T> *__restrict__ m
 
 template <typename T>
 __global__ __launch_bounds__(WAVE) void k_sim(const DevModel<T> *__restrict__ mp, int n, const T *q_tsid, T *qpos, T *qvel,
-                                              T *qacc_ws, const T *env_params, T *qacc, int *ncon, int *con, int *info) {
+                                              T *qacc_ws, const T *env_params, const T *motor_tau, T *qacc, int *ncon,
+                                              int *con, int *info) {
   __shared__ SimLds<T> L;
   const int e = blockIdx.x, lane = threadIdx.x;
   if (e >= n) return;
   const size_t E = (size_t)e;
   sim_step_env<T>(*mp, L, lane, q_tsid ? q_tsid + E * NQ : nullptr, qpos + E * NQ, qvel + E * NV, qacc_ws + E * NV,
-                  env_params ? env_params + E * 8 : nullptr, qacc ? qacc + E * NV : nullptr, ncon ? ncon + e : nullptr, con ? con + E * MAXCON : nullptr,
+                  env_params ? env_params + E * 8 : nullptr, motor_tau ? motor_tau + E * NA : nullptr,
+                  qacc ? qacc + E * NV : nullptr, ncon ? ncon + e : nullptr, con ? con + E * MAXCON : nullptr,
                   info ? info + E * 4 : nullptr);
 }
 
@@ -95,7 +99,7 @@ __global__ __launch_bounds__(WAVE) void k_reset(const DevModel<T> *__restrict__ 
   if (lane < NV) { v[E * NV + lane] = 0; qvel[E * NV + lane] = 0; qacc_ws[E * NV + lane] = 0; }
   if (lane < NQ) {
     T val = L.qs[lane]; // main.py:64: raw copy (quirks F6a/F6b); joints are all zero in "standing"
-    if (m.params[P_QUIRKS] == 0) {
+    if (m.params[P_QUIRKS] == 0 || m.params[P_CLOSED_LOOP] != 0) {
       if (lane == 3) val = L.qs[6];
       else if (lane > 3 && lane < 7) val = L.qs[lane - 1];
       else if (lane >= 7) val = L.qs[m.mj_ctrl_qidx[lane - 7]];
@@ -375,6 +379,7 @@ static void build_model(tsidb_ctx *h, DevModel<T> &m) {
   for (int i = 0; i < NB * 2; i++) m.mj_body_invw0[i / 2][i % 2] = (T)bw[i];
   memcpy(m.mj_act_dof, b.i32("mj_act_dof", NA), sizeof m.mj_act_dof);
   memcpy(m.mj_ctrl_qidx, b.i32("mj_ctrl_qidx", NA), sizeof m.mj_ctrl_qidx);
+  for (int a2 = 0; a2 < NA; a2++) m.tsid2sim[m.mj_ctrl_qidx[a2] - 7] = a2;
   const double *kp = b.f64("mj_act_kp", NA), *kv = b.f64("mj_act_kv", NA);
   for (int i = 0; i < NA; i++) { m.mj_act_kp[i] = (T)kp[i]; m.mj_act_kv[i] = (T)kv[i]; }
   memcpy(m.hull_adr, b.i32("mj_hull_adr", NB + 1), sizeof m.hull_adr);
@@ -447,18 +452,19 @@ static void need_refs(tsidb_ctx *h) {
 
 template <typename T>
 static void launch_tick(tsidb_ctx *h, void *q, void *v, void *tau, void *dv, void *f, int32_t *status, void *obs,
-                        void *frames, int32_t *info, hipStream_t s) {
+                        void *frames, int32_t *info, hipStream_t s, const void *qpos_sim = nullptr,
+                        const void *qvel_sim = nullptr) {
   hipLaunchKernelGGL(k_tick<T>, dim3(h->num_envs), dim3(WAVE), 0, s, (const DevModel<T> *)h->d_model, h->num_envs, (T *)q,
                      (T *)v, (const T *)h->com_ref, (const T *)h->posture_ref, (const T *)h->foot_ref,
                      (const T *)h->contact_ref, h->contact_active, (const T *)h->cop_frames, (T *)tau, (T *)dv, (T *)f,
-                     status, (T *)obs, (T *)frames, info);
+                     status, (T *)obs, (T *)frames, info, (const T *)qpos_sim, (const T *)qvel_sim);
   HIP_OK(hipGetLastError());
 }
 template <typename T>
 static void launch_sim(tsidb_ctx *h, const void *q_tsid, void *qpos, void *qvel, void *qacc_ws, void *qacc, int32_t *ncon,
-                       int32_t *con, int32_t *info, hipStream_t s) {
+                       int32_t *con, int32_t *info, hipStream_t s, const void *motor_tau = nullptr) {
   hipLaunchKernelGGL(k_sim<T>, dim3(h->num_envs), dim3(WAVE), 0, s, (const DevModel<T> *)h->d_model, h->num_envs,
-                     (const T *)q_tsid, (T *)qpos, (T *)qvel, (T *)qacc_ws, (const T *)h->env_params, (T *)qacc, ncon, con, info);
+                     (const T *)q_tsid, (T *)qpos, (T *)qvel, (T *)qacc_ws, (const T *)h->env_params, (const T *)motor_tau, (T *)qacc, ncon, con, info);
   HIP_OK(hipGetLastError());
 }
 
@@ -570,16 +576,17 @@ int tsidb_step(tsidb_handle h, void *q, void *v, void *qpos, void *qvel, void *q
   GUARD_BEGIN
   need_refs(h);
   if (!q || !v || !tau || !dv || !f || !status) throw std::string("tsidb_step: null buffer");
-  const bool sim = h->params[P_SIM_ENABLED] != 0.0;
+  const bool sim = h->params[P_SIM_ENABLED] != 0.0, closed = h->params[P_CLOSED_LOOP] != 0.0;
   if (sim && (!qpos || !qvel || !qacc_ws)) throw std::string("tsidb_step: null sim state buffer");
   hipStream_t s = (hipStream_t)stream;
   for (int it = 0; it < n_substeps; it++) {
+    // closed loop: the tick reads the sim state, the sim is driven by tau and keeps its own base pose
     if (h->dtype == TSIDB_F64) {
-      launch_tick<double>(h, q, v, tau, dv, f, status, obs, frames, info, s);
-      if (sim) launch_sim<double>(h, q, qpos, qvel, qacc_ws, nullptr, ncon, con_pairs, info, s);
+      launch_tick<double>(h, q, v, tau, dv, f, status, obs, frames, info, s, closed ? qpos : nullptr, closed ? qvel : nullptr);
+      if (sim) launch_sim<double>(h, closed ? nullptr : q, qpos, qvel, qacc_ws, nullptr, ncon, con_pairs, info, s, closed ? tau : nullptr);
     } else {
-      launch_tick<float>(h, q, v, tau, dv, f, status, obs, frames, info, s);
-      if (sim) launch_sim<float>(h, q, qpos, qvel, qacc_ws, nullptr, ncon, con_pairs, info, s);
+      launch_tick<float>(h, q, v, tau, dv, f, status, obs, frames, info, s, closed ? qpos : nullptr, closed ? qvel : nullptr);
+      if (sim) launch_sim<float>(h, closed ? nullptr : q, qpos, qvel, qacc_ws, nullptr, ncon, con_pairs, info, s, closed ? tau : nullptr);
     }
   }
   GUARD_END

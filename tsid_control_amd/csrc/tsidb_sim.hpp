@@ -161,7 +161,8 @@ __device__ __forceinline__ void rows_eval(const RowState<T> &rs, T alpha, T &c, 
 
 template <typename T>
 __device__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L, int lane, const T *q_tsid, T *qpos_g, T *qvel_g,
-                             T *qacc_ws_g, const T *envp, T *qacc_out, int *ncon_out, int *con_out, int *info) {
+                             T *qacc_ws_g, const T *envp, const T *motor_tau, T *qacc_out, int *ncon_out, int *con_out,
+                             int *info) {
   // per-env randomisation (BASELINE config 5), NULL = nominal: mass scale, contact friction, floor plane
   const T mscale = envp ? envp[0] : T(1);
   Floor<T> fl;
@@ -363,7 +364,9 @@ __device__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L, int lane, const
   if (lane < NV) L.M[lane * LDM + lane] += m.mj_armature[lane];
   if (lane < NA) {
     const int d = m.mj_act_dof[lane];
-    L.xv[d] = m.mj_act_kp[lane] * (L.ctrl[lane] - L.qpos[d + 1]) - m.mj_act_kv[lane] * L.qvel[d];
+    // closed loop: TSID's joint torques as motor forces; otherwise the reference's position servos
+    L.xv[d] = motor_tau ? motor_tau[m.mj_ctrl_qidx[lane] - 7]
+                        : m.mj_act_kp[lane] * (L.ctrl[lane] - L.qpos[d + 1]) - m.mj_act_kv[lane] * L.qvel[d];
   } else if (lane >= 32 && lane < 38) L.xv[lane - 32] = 0;
   __syncthreads();
   if (lane < NV) { qfs += L.xv[lane]; L.qfs[lane] = qfs; }

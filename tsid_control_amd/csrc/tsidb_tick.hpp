@@ -896,11 +896,34 @@ template <typename T, int NS>
 __device__ void tsid_tick_env(const DevModel<T> &m, TickLds<T> &L, int lane, T *q, T *v, const T *com_ref,
                               const T *posture_ref, const T *foot_ref, const T *contact_ref,
                               const uint8_t *cact, const T *cop_frames, T *tau, T *dv, T *fout, int *status_out,
-                              T *obs, int *info) {
+                              T *obs, int *info, const T *qpos_sim, const T *qvel_sim) {
   TSIDB_STAMP(0);
-  // ---- stage state
-  if (lane < NQ) L.qs[lane] = q[lane];
-  if (lane < NV) L.vs[lane] = v[lane];
+  // ---- stage state.  Closed loop: the TSID state is read from the sim state each
+  //      tick - quat wxyz -> xyzw, world-frame base linear velocity -> body frame, sim joint order ->
+  //      TSID joint order; otherwise TSID integrates its own state as the reference does (main.py:128).
+  if (qpos_sim) {
+    if (lane < NQ) {
+      T val;
+      if (lane < 3) val = qpos_sim[lane];
+      else if (lane < 6) val = qpos_sim[lane + 1];
+      else if (lane == 6) val = qpos_sim[3];
+      else val = qpos_sim[7 + m.tsid2sim[lane - 7]];
+      L.qs[lane] = val;
+    }
+    if (lane < NV) {
+      T val;
+      if (lane < 3) {
+        T R[9];
+        quat_to_R(qpos_sim[4], qpos_sim[5], qpos_sim[6], qpos_sim[3], R);
+        val = R[lane] * qvel_sim[0] + R[3 + lane] * qvel_sim[1] + R[6 + lane] * qvel_sim[2];
+      } else if (lane < 6) val = qvel_sim[lane];
+      else val = qvel_sim[6 + m.tsid2sim[lane - 6]];
+      L.vs[lane] = val;
+    }
+  } else {
+    if (lane < NQ) L.qs[lane] = q[lane];
+    if (lane < NV) L.vs[lane] = v[lane];
+  }
   __syncthreads();
   rbd_terms(m, L, lane);
   TSIDB_STAMP(1);

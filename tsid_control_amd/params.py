@@ -29,6 +29,7 @@ P_TAU_MAX = 71
 P_V_MAX = 91
 P_MAX_ITER = 111
 P_SIM_ENABLED = 112
+P_CLOSED_LOOP = 113
 P_COUNT = 128
 
 
@@ -65,4 +66,7 @@ def pack_params(conf, effort_limit, velocity_limit):
     p[P_V_MAX:P_V_MAX + 20] = conf.v_max_scaling * np.asarray(velocity_limit)
     p[P_MAX_ITER] = getattr(conf, "qp_max_iter", 1000)
     p[P_SIM_ENABLED] = 1.0 if getattr(conf, "sim_enabled", True) else 0.0
+    p[P_CLOSED_LOOP] = 1.0 if getattr(conf, "closed_loop", False) else 0.0
+    if p[P_CLOSED_LOOP] and not p[P_SIM_ENABLED]:
+        raise ValueError("closed_loop needs the sim stage (sim_enabled=True)")
     return p
