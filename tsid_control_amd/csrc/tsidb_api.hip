@@ -14,32 +14,29 @@
 using namespace tsidb;
 
 // ============================================================================ kernels
-template <typename T>
-__global__ __launch_bounds__(WAVE) void k_tick(const DevModel<T> *__restrict__ mp, int n, T *q, T *v, const T *com_ref,
-                                               const T *posture_ref, const T *foot_ref, const T *contact_ref,
-                                               const uint8_t *cact, const T *cop_frames, T *tau, T *dv, T *f,
-                                               int *status, T *obs, T *frames, int *info, const T *qpos_sim,
-                                               const T *qvel_sim) {
+// One kernel per contact configuration (NS feet in contact): each variant gets its own register
+// allocation (NS = 2 keeps 2 x 50 float64 rows/columns in registers, NS = 1 only 2 x 38), and a
+// workgroup whose env is in another configuration exits at once.  All three are launched every tick.
+template <typename T, int NS>
+__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_tick(const DevModel<T> *__restrict__ mp, int n, T *q, T *v, const T *com_ref,
+                                                  const T *posture_ref, const T *foot_ref, const T *contact_ref,
+                                                  const uint8_t *cact, const T *cop_frames, T *tau, T *dv, T *f,
+                                                  int *status, T *obs, T *frames, int *info, const T *qpos_sim,
+                                                  const T *qvel_sim) {
   __shared__ TickLds<T> L;
   const int e = blockIdx.x, lane = threadIdx.x;
   if (e >= n) return;
   const size_t E = (size_t)e;
-  // the contact configuration is known before anything is computed: run the variant compiled for it
-  const int nslot = (cact[E * 2] != 0) + (cact[E * 2 + 1] != 0);
-#define TSIDB_TICK_ARGS                                                                                                    \
-  *mp, L, lane, q + E * NQ, v + E * NV, com_ref + E * 9, posture_ref + E * NA, foot_ref + E * 48, contact_ref + E * 24,  \
-      cact + E * 2, cop_frames ? cop_frames + E * 24 : nullptr, tau + E * NA, dv + E * NV, f + E * 24, status + e,       \
-      obs ? obs + E * NOBS : nullptr, info ? info + E * 4 : nullptr, qpos_sim ? qpos_sim + E * NQ : nullptr,    \
-      qvel_sim ? qvel_sim + E * NV : nullptr
-  if (nslot == 2) tsid_tick_env<T, 2>(TSIDB_TICK_ARGS);
-  else if (nslot == 1) tsid_tick_env<T, 1>(TSIDB_TICK_ARGS);
-  else tsid_tick_env<T, 0>(TSIDB_TICK_ARGS);
-#undef TSIDB_TICK_ARGS
+  if ((cact[E * 2] != 0) + (cact[E * 2 + 1] != 0) != NS) return;
+  tsid_tick_env<T, NS>(*mp, L, lane, q + E * NQ, v + E * NV, com_ref + E * 9, posture_ref + E * NA, foot_ref + E * 48,
+                       contact_ref + E * 24, cact + E * 2, cop_frames ? cop_frames + E * 24 : nullptr, tau + E * NA,
+                       dv + E * NV, f + E * 24, status + e, obs ? obs + E * NOBS : nullptr, info ? info + E * 4 : nullptr,
+                       qpos_sim ? qpos_sim + E * NQ : nullptr, qvel_sim ? qvel_sim + E * NV : nullptr);
   if (frames && lane < 24) frames[E * 24 + lane] = L.oMf[lane / 12][lane % 12];
 }
 
 template <typename T>
-__global__ __launch_bounds__(WAVE) void k_sim(const DevModel<T> *__restrict__ mp, int n, const T *q_tsid, T *qpos, T *qvel,
+__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_sim(const DevModel<T> *__restrict__ mp, int n, const T *q_tsid, T *qpos, T *qvel,
                                               T *qacc_ws, const T *env_params, const T *motor_tau, T *qacc, int *ncon,
                                               int *con, int *info) {
   __shared__ SimLds<T> L;
@@ -454,10 +451,15 @@ template <typename T>
 static void launch_tick(tsidb_ctx *h, void *q, void *v, void *tau, void *dv, void *f, int32_t *status, void *obs,
                         void *frames, int32_t *info, hipStream_t s, const void *qpos_sim = nullptr,
                         const void *qvel_sim = nullptr) {
-  hipLaunchKernelGGL(k_tick<T>, dim3(h->num_envs), dim3(WAVE), 0, s, (const DevModel<T> *)h->d_model, h->num_envs, (T *)q,
-                     (T *)v, (const T *)h->com_ref, (const T *)h->posture_ref, (const T *)h->foot_ref,
-                     (const T *)h->contact_ref, h->contact_active, (const T *)h->cop_frames, (T *)tau, (T *)dv, (T *)f,
-                     status, (T *)obs, (T *)frames, info, (const T *)qpos_sim, (const T *)qvel_sim);
+#define TSIDB_LAUNCH_TICK(NS)                                                                                              \
+  hipLaunchKernelGGL((k_tick<T, NS>), dim3(h->num_envs), dim3(WAVE), 0, s, (const DevModel<T> *)h->d_model, h->num_envs,   \
+                     (T *)q, (T *)v, (const T *)h->com_ref, (const T *)h->posture_ref, (const T *)h->foot_ref,             \
+                     (const T *)h->contact_ref, h->contact_active, (const T *)h->cop_frames, (T *)tau, (T *)dv, (T *)f,    \
+                     status, (T *)obs, (T *)frames, info, (const T *)qpos_sim, (const T *)qvel_sim)
+  TSIDB_LAUNCH_TICK(2);
+  TSIDB_LAUNCH_TICK(1);
+  TSIDB_LAUNCH_TICK(0);
+#undef TSIDB_LAUNCH_TICK
   HIP_OK(hipGetLastError());
 }
 template <typename T>

@@ -233,7 +233,7 @@ template <typename T> __device__ __forceinline__ void cross_mf(const T *v, const
 }
 
 // log6 of a relative placement (R row-major, p) -> [v; w]   (pinocchio::log6 semantics)
-template <typename T> __device__ inline void log6(const T *R, const T *p, T *out) {
+template <typename T> __device__ __forceinline__ void log6(const T *R, const T *p, T *out) {
   const T PI = T(3.14159265358979323846);
   T tr = R[0] + R[4] + R[8];
   T ct = T(0.5) * (tr - 1);

@@ -34,8 +34,8 @@ struct SimLds {
     T H[NV * LDM];
     T Wc[MAXCON][21];
   };
-  T qpos[NQ], qvel[NV], ctrl[NA];
-  T qfs[NV], qas[NV], bias[NV], xv[NV];
+  T qpos[NQ], qvel[NV];
+  T xv[NV];
   int cbody[MAXCON], cvert[MAXCON];
   unsigned anc[NB]; // ancestor bitmask per body (copied from the model: LDS latency, not global)
   T cr[MAXCON][3], cdist[MAXCON], cfv[MAXCON][3]; // contact point (rel O), distance, force vector
@@ -160,7 +160,7 @@ __device__ __forceinline__ void rows_eval(const RowState<T> &rs, T alpha, T &c, 
 }
 
 template <typename T>
-__device__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L, int lane, const T *q_tsid, T *qpos_g, T *qvel_g,
+__device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L, int lane, const T *q_tsid, T *qpos_g, T *qvel_g,
                              T *qacc_ws_g, const T *envp, const T *motor_tau, T *qacc_out, int *ncon_out, int *con_out,
                              int *info) {
   // per-env randomisation (BASELINE config 5), NULL = nominal: mass scale, contact friction, floor plane
@@ -198,7 +198,7 @@ __device__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L, int lane, const
     L.qpos[lane] = val;
   }
   if (lane < NV) L.qvel[lane] = qvel_g[lane];
-  if (lane < NA) L.ctrl[lane] = q_tsid ? q_tsid[m.mj_ctrl_qidx[lane]] : T(0);
+  const T myctrl = (lane < NA && q_tsid) ? q_tsid[m.mj_ctrl_qidx[lane]] : T(0); // joint target of actuator `lane`
   for (int i = lane; i < NV * LDM; i += WAVE) L.M[i] = 0;
   __syncthreads();
   const T Oz = L.qpos[2];
@@ -344,7 +344,6 @@ __device__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L, int lane, const
     T Sk[6], Fk[6], hk = 0;
 #pragma unroll
     for (int i = 0; i < 6; i++) { Sk[i] = L.S[k][i]; hk += Sk[i] * L.f[bk][i]; }
-    L.bias[k] = hk;
     yo_mul(L.Yc[bk], Sk, Fk);
     for (unsigned mk = dofanc; mk; mk &= mk - 1) {
       const int a = __ffs(mk) - 1;
@@ -366,10 +365,10 @@ __device__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L, int lane, const
     const int d = m.mj_act_dof[lane];
     // closed loop: TSID's joint torques as motor forces; otherwise the reference's position servos
     L.xv[d] = motor_tau ? motor_tau[m.mj_ctrl_qidx[lane] - 7]
-                        : m.mj_act_kp[lane] * (L.ctrl[lane] - L.qpos[d + 1]) - m.mj_act_kv[lane] * L.qvel[d];
+                        : m.mj_act_kp[lane] * (myctrl - L.qpos[d + 1]) - m.mj_act_kv[lane] * L.qvel[d];
   } else if (lane >= 32 && lane < 38) L.xv[lane - 32] = 0;
   __syncthreads();
-  if (lane < NV) { qfs += L.xv[lane]; L.qfs[lane] = qfs; }
+  if (lane < NV) qfs += L.xv[lane];
   TSIDB_STAMP(17);
   // ---- qacc_smooth = M^-1 qfrc_smooth
   T arow[NV];
@@ -378,7 +377,6 @@ __device__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L, int lane, const
   bool spd;
   const T qas = chol26_solve(arow, qfs, lane, spd);
   int fail = spd ? 0 : 1;
-  if (lane < NV) L.qas[lane] = qas;
 
   TSIDB_STAMP(18);
   // ---- collision: floor plane (n.x = d; nominal z = 0) against each body's convex hull

@@ -83,7 +83,7 @@ __device__ __forceinline__ double rdlane(double v, int src) {
 // Inputs L.qs, L.vs.  Outputs: L.Dyn (M part, rest zero), L.h, L.Jf, L.Jcom, L.oMf, L.vf, L.af,
 // L.com, L.vcom, L.acomd.  Spatial vectors are [lin; ang] in world axes about the base origin O.
 template <typename T>
-__device__ void rbd_terms(const DevModel<T> &m, TickLds<T> &L, int lane) {
+__device__ __forceinline__ void rbd_terms(const DevModel<T> &m, TickLds<T> &L, int lane) {
   KinScratch<T> &K = L.k;
   const T GZ = T(9.81);
   for (int i = lane; i < NV * LDD; i += WAVE) L.Dyn[i] = 0;
@@ -310,7 +310,7 @@ __device__ void rbd_terms(const DevModel<T> &m, TickLds<T> &L, int lane) {
 // --------------------------------------------------------------------------- task right-hand sides
 // TaskSE3Equality in the local frame: kp*log6(M^-1 Mref) + kd*(R^T vref - v) + R^T aref - drift
 template <typename T>
-__device__ void se3_rhs(const TickLds<T> &L, int f, const T *ref, int nref, T kp, T kd, T *rhs) {
+__device__ __forceinline__ void se3_rhs(const TickLds<T> &L, int f, const T *ref, int nref, T kp, T kd, T *rhs) {
   const T *R = L.oMf[f], *p = L.oMf[f] + 9;
   T rel[9], d[3], pr[3], err[6];
 #pragma unroll
@@ -893,7 +893,7 @@ __device__ __forceinline__ void tick_qp(const DevModel<T> &m, TickLds<T> &L, QpC
 
 // --------------------------------------------------------------------------- the tick
 template <typename T, int NS>
-__device__ void tsid_tick_env(const DevModel<T> &m, TickLds<T> &L, int lane, T *q, T *v, const T *com_ref,
+__device__ __forceinline__ void tsid_tick_env(const DevModel<T> &m, TickLds<T> &L, int lane, T *q, T *v, const T *com_ref,
                               const T *posture_ref, const T *foot_ref, const T *contact_ref,
                               const uint8_t *cact, const T *cop_frames, T *tau, T *dv, T *fout, int *status_out,
                               T *obs, int *info, const T *qpos_sim, const T *qvel_sim) {
