@@ -76,12 +76,14 @@ int tsidb_reset(tsidb_handle h, const int32_t *env_ids, int n_ids, void *q, void
 int tsidb_tick(tsidb_handle h, void *q, void *v, void *tau, void *dv, void *f, int32_t *status, void *obs,
                void *frames, int32_t *info, void *stream);
 
-/* one sim step for every env: main.py:192-195.  q_tsid [N,27] (NULL = no teleport, ctrl = 0),
- * qpos [N,27], qvel [N,26], qacc_ws [N,26] updated in place; qacc [N,26], ncon [N],
+/* one sim step for every env: main.py:192-195.  q_tsid [N,27] (NULL = no teleport, ctrl = 0); v_tsid
+ * [N,26] (may be NULL) is used only with params[QUIRKS] = 0: the base velocity is then set together with
+ * the base pose (the reference writes qpos[:7] only, which leaves the sim's base velocity to drift once
+ * the TSID state moves).  qpos [N,27], qvel [N,26], qacc_ws [N,26] updated in place; qacc [N,26], ncon [N],
  * con_pairs [N,32] = (body << 16 | hull vertex), -1 padded; info [N,4] slots 2,3 = solver
  * iterations, failure bits (all may be NULL). */
-int tsidb_sim(tsidb_handle h, const void *q_tsid, void *qpos, void *qvel, void *qacc_ws, void *qacc,
-              int32_t *ncon, int32_t *con_pairs, int32_t *info, void *stream);
+int tsidb_sim(tsidb_handle h, const void *q_tsid, const void *v_tsid, void *qpos, void *qvel, void *qacc_ws,
+              void *qacc, int32_t *ncon, int32_t *con_pairs, int32_t *info, void *stream);
 
 /* whole env step, n_substeps times: tsidb_tick then (if params[SIM_ENABLED]) tsidb_sim.
  * With params[CLOSED_LOOP] (not in the reference, whose coupling is one-way, main.py:126-129,
@@ -97,12 +99,17 @@ int tsidb_step(tsidb_handle h, void *q, void *v, void *qpos, void *qvel, void *q
  * come from ctrl/Walk_Planner.py:23-31 swing trajectories (ctrl/Foot_Trajectory.py polynomials) over
  * a ctrl/Footstep_Planner.py plan.  coef [N,K,4,4] = x, y, z, yaw cubic coefficients (ascending, in
  * time since the step started); side [N,K] int32 = swinging foot of step k (0 left); nsteps [N] int32;
- * rest [N,K+1,2,3] = (x, y, yaw) of [left, right] foot before step k.  Writes the registered
- * foot_ref / contact_ref / contact_active / com_ref[:, 0:2] buffers; contact on/off edges re-reference
- * at `frames` [N,2,12] (current sole placements from the last tsidb_tick), as
+ * rest [N,K+1,2,4] = (x, y, yaw, z) of [left, right] foot before step k; com [N,K+2,2,3] = linear-inverted-
+ * pendulum segment (zmp, d, c) per planar axis for the start phase, each step and the final stand
+ * (ctrl/LIPM.py:34-49 about a fixed ZMP, in closed form x(s) = zmp + d/2 e^{omega s} + c e^{-omega s}).
+ * Timeline: [0, t_start) both feet down while the CoM height goes from com_z0 to com_z0 - com_drop; step
+ * k occupies [t_start + k T, t_start + (k+1) T); afterwards both feet are down.  Writes the registered
+ * foot_ref / contact_ref / contact_active / com_ref (position, velocity, acceleration) buffers; contact
+ * on/off edges re-reference at `frames` [N,2,12] (current sole placements from the last tsidb_tick), as
  * ctrl/WalkController.py:215-253 intends. */
 int tsidb_walk_update(tsidb_handle h, const void *coef, const int32_t *side, const int32_t *nsteps,
-                      const void *rest, int K, double t, double step_duration, const void *frames, void *stream);
+                      const void *rest, const void *com, int K, double t, double step_duration, double t_start,
+                      double omega, double com_z0, double com_drop, const void *frames, void *stream);
 
 /* probe of formulation.computeProblemData's rigid-body terms (main.py:119): M [N,26,26],
  * hbias [N,26], Jcom [N,3,26], Jf [N,2,6,26] (LOCAL), oMf [N,2,12], com [N,3].  Test/debug use. */

@@ -54,7 +54,17 @@ int or_env_step_batch_env(const OrModel *m, const double *params, int n, double 
       /* main.py:192  mj_data.qpos[:7] = q[:7]  (quirk F6a: xyzw copied into the wxyz slot) */
       for (int i = 0; i < 3; i++) qp[i] = qe[i];
       if (quirks) for (int i = 0; i < 4; i++) qp[3 + i] = qe[3 + i];
-      else { qp[3] = qe[6]; qp[4] = qe[3]; qp[5] = qe[4]; qp[6] = qe[5]; }
+      else {
+        qp[3] = qe[6]; qp[4] = qe[3]; qp[5] = qe[4]; qp[6] = qe[5];
+        /* without the quirks the base is teleported with its velocity (the reference leaves qvel alone):
+         * TSID linear velocity is in the body frame, the sim's in the world frame */
+        const double x = qe[3], y = qe[4], z = qe[5], w = qe[6];
+        const double R[9] = {1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y),
+                             2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x),
+                             2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)};
+        for (int i = 0; i < 3; i++) qv[i] = R[3 * i] * ve[0] + R[3 * i + 1] * ve[1] + R[3 * i + 2] * ve[2];
+        for (int i = 3; i < 6; i++) qv[i] = ve[i];
+      }
       /* main.py:193-194  ctrl = map_tsid_to_mujoco(q) */
       for (int a = 0; a < OR_NA; a++) ctrl[a] = qe[m->mj_ctrl_qidx[a]];
     }

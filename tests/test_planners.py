@@ -99,3 +99,69 @@ def test_walk_planner_swings_i_to_i_plus_2():
         assert np.allclose(sw.get_position(0.0)[:2], steps[i].position)
         assert np.allclose(sw.get_position(conf.step_duration)[:2], steps[i + 2].position)
         assert abs(sw.get_position(conf.step_duration / 2)[2] - conf.step_height) < 1e-12
+
+
+def _schedule(n=3, seed=4, **kw):
+    import torch
+    from tsid_control_amd.conf import RobotConfig
+    from tsid_control_amd.walk_planner import WalkSchedule, op3_walking_conf
+    conf = op3_walking_conf(RobotConfig())
+    lf, rf = np.array([0.0424, 0.0446]), np.array([-0.0424, 0.0446])   # the OP3's soles at the standing pose
+    com0 = np.array([0.001, 0.052, 0.2414])
+    return WalkSchedule.from_demo_paths(n, conf, "cpu", torch.float64, seed=seed, q0_feet=(lf, rf), com0=com0, **kw), conf, lf, rf, com0
+
+
+def test_walk_schedule_com_reference_is_a_lipm_motion():
+    """com_ref(t): starts at rest at the initial CoM, is C1 across every phase boundary, obeys the LIPM
+    equation acc = w^2 (pos - zmp) with the ZMP on the stance foot of each step (LIPM.py:44), and comes to
+    rest between the last two footsteps."""
+    sched, conf, lf, rf, com0 = _schedule()
+    T, t0, w = conf.step_duration, sched.t_start, sched.omega
+    r = sched.com_ref(0.0).numpy()
+    assert np.allclose(r[:, :2], com0[:2], atol=1e-12) and np.abs(r[:, 3:5]).max() < 1e-12
+    assert np.allclose(r[:, 2], com0[2]) and np.allclose(sched.com_ref(t0 + 1.0).numpy()[:, 2], com0[2] - sched.dz)
+    ns = sched.nsteps.numpy()
+    for k in range(0, int(ns.max()) + 2):
+        tb = t0 + k * T
+        a, b = sched.com_ref(tb - 1e-9).numpy(), sched.com_ref(tb + 1e-9).numpy()
+        assert np.abs(a[:, :6] - b[:, :6]).max() < 1e-6, k          # position and velocity continuous
+    # LIPM equation inside the steps: the ZMP is where the stance foot rests
+    for k in (0, 1, 5, 11):
+        t = t0 + (k + 0.37) * T
+        r = sched.com_ref(t).numpy()
+        zmp = r[:, 0:2] - r[:, 6:8] / w ** 2
+        sLF, sRF, cLF, cRF = sched.sample(t)
+        stance = np.where(cLF.numpy()[:, None], sLF.numpy()[:, :2], sRF.numpy()[:, :2])
+        assert (cLF ^ cRF).all() and np.abs(zmp - stance).max() < 1e-9, k
+    # after the plan: both feet down, CoM settles between them
+    t_end = t0 + (int(ns.max()) + 4) * T
+    r = sched.com_ref(t_end).numpy()
+    sLF, sRF, cLF, cRF = sched.sample(t_end)
+    assert cLF.all() and cRF.all()
+    mid = 0.5 * (sLF.numpy()[:, :2] + sRF.numpy()[:, :2])
+    assert np.abs(r[:, :2] - mid).max() < 1e-3 and np.abs(r[:, 3:5]).max() < 1e-2
+
+
+def test_walk_schedule_heading_and_phases():
+    """The demo path is laid along the robot's own heading (left foot stays on the left), both feet
+    stay down until t_start, then the feet alternate, each swing starting and ending on its footsteps."""
+    sched, conf, lf, rf, com0 = _schedule(t_start=0.4)
+    sLF, sRF, cLF, cRF = sched.sample(0.2)
+    assert cLF.all() and cRF.all()
+    assert np.allclose(sLF.numpy()[:, :2], lf) and np.allclose(sRF.numpy()[:, :2], rf)
+    assert np.allclose(sLF.numpy()[:, 3:12], np.eye(3).reshape(-1))   # yaw relative to the initial heading
+    T = conf.step_duration
+    prev = None
+    for k in range(6):
+        sLF, sRF, cLF, cRF = sched.sample(0.4 + (k + 0.5) * T)
+        assert (cLF ^ cRF).all()
+        if prev is not None:
+            assert (cLF == ~prev).all()
+        prev = cLF
+        swing = np.where(cLF.numpy()[:, None], sRF.numpy(), sLF.numpy())
+        assert np.allclose(swing[:, 2], conf.step_height, atol=0.0021)   # apex of the parabola (a12), above a pressed foot
+    # walking direction: the left foot (at +x of the right one) is to the left of the direction of travel
+    end = sched.rest[:, 6].numpy()                                    # feet before step 6
+    fwd = 0.5 * (end[:, 0, :2] + end[:, 1, :2]) - 0.5 * (lf + rf)
+    left = lf - rf
+    assert (left[0] * fwd[:, 1] - left[1] * fwd[:, 0] < 0).all() and (np.linalg.norm(fwd, axis=1) > 0.1).all()

@@ -11,12 +11,17 @@ from tsid_control_amd import RobotConfig, WalkController, _lib
 dtype = sys.argv[1] if len(sys.argv) > 1 else "f64"
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 conf = RobotConfig(); conf.dtype = dtype
+WALK = len(sys.argv) > 3 and sys.argv[3] == "walk"
+if WALK:
+    from tsid_control_amd.walk_planner import op3_walking_conf, op3_walking_posture
+    op3_walking_conf(conf); conf.reference_quirks = False
 wc = WalkController(conf, num_envs=N)
 torch.manual_seed(0)
 if len(sys.argv) > 3 and sys.argv[3] == "walk":
     from tsid_control_amd.walk_planner import WalkSchedule
     lf, rf = wc.frames[0, 0, 9:11].cpu().numpy(), wc.frames[0, 1, 9:11].cpu().numpy()
-    sched = WalkSchedule.from_demo_paths(N, conf, wc.device, wc.dtype, seed=1, q0_feet=(lf, rf))
+    wc.posture_ref += torch.as_tensor(op3_walking_posture(), device=wc.device).to(wc.dtype)
+    sched = WalkSchedule.from_demo_paths(N, conf, wc.device, wc.dtype, seed=1, q0_feet=(lf, rf), com0=wc.com_ref[0, :3].double().cpu().numpy())
     for i in range(int(sys.argv[4]) if len(sys.argv) > 4 else 100):
         sched.apply(wc, i * conf.dt); wc.step()
 else:

@@ -18,7 +18,7 @@ using namespace tsidb;
 // allocation (NS = 2 keeps 2 x 50 float64 rows/columns in registers, NS = 1 only 2 x 38), and a
 // workgroup whose env is in another configuration exits at once.  All three are launched every tick.
 template <typename T, int NS>
-__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_tick(const DevModel<T> *__restrict__ mp, int n, T *q, T *v, const T *com_ref,
+__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2))) void k_tick(const DevModel<T> *__restrict__ mp, int n, T *q, T *v, const T *com_ref,
                                                   const T *posture_ref, const T *foot_ref, const T *contact_ref,
                                                   const uint8_t *cact, const T *cop_frames, T *tau, T *dv, T *f,
                                                   int *status, T *obs, T *frames, int *info, const T *qpos_sim,
@@ -36,14 +36,14 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
 }
 
 template <typename T>
-__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_sim(const DevModel<T> *__restrict__ mp, int n, const T *q_tsid, T *qpos, T *qvel,
+__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2))) void k_sim(const DevModel<T> *__restrict__ mp, int n, const T *q_tsid, const T *v_tsid, T *qpos, T *qvel,
                                               T *qacc_ws, const T *env_params, const T *motor_tau, T *qacc, int *ncon,
                                               int *con, int *info) {
   __shared__ SimLds<T> L;
   const int e = blockIdx.x, lane = threadIdx.x;
   if (e >= n) return;
   const size_t E = (size_t)e;
-  sim_step_env<T>(*mp, L, lane, q_tsid ? q_tsid + E * NQ : nullptr, qpos + E * NQ, qvel + E * NV, qacc_ws + E * NV,
+  sim_step_env<T>(*mp, L, lane, q_tsid ? q_tsid + E * NQ : nullptr, v_tsid ? v_tsid + E * NV : nullptr, qpos + E * NQ, qvel + E * NV, qacc_ws + E * NV,
                   env_params ? env_params + E * 8 : nullptr, motor_tau ? motor_tau + E * NA : nullptr,
                   qacc ? qacc + E * NV : nullptr, ncon ? ncon + e : nullptr, con ? con + E * MAXCON : nullptr,
                   info ? info + E * 4 : nullptr);
@@ -122,19 +122,21 @@ __global__ __launch_bounds__(WAVE) void k_reset(const DevModel<T> *__restrict__ 
 
 // walking reference update: one lane per env (Walk_Planner.py:23-31 samples -> WalkController.py:189-253)
 template <typename T>
-__global__ __launch_bounds__(256) void k_walk(int n, const T *coef, const int *side, const int *nsteps, const T *rest, int K,
-                                              T t, T Tstep, const T *frames, T *foot_ref, T *contact_ref, uint8_t *cact,
-                                              T *com_ref) {
+__global__ __launch_bounds__(256) void k_walk(int n, const T *coef, const int *side, const int *nsteps, const T *rest, const T *com,
+                                              int K, T t, T Tstep, T t_start, T omega, T z0, T dz, const T *frames, T *foot_ref,
+                                              T *contact_ref, uint8_t *cact, T *com_ref) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n) return;
   const size_t E = (size_t)e;
-  const int k = (int)floor(t / Tstep);
-  const T s = t - k * Tstep;
+  // timeline: [0, t_start) both feet down; step k in [t_start + k T, t_start + (k+1) T); then the final stand
+  const int k = t < t_start ? -1 : (int)floor((t - t_start) / Tstep);
+  const T s = k < 0 ? t : (t - t_start) - k * Tstep;
   const int ns = nsteps[e];
-  const bool walking = k < ns;
-  const int kc = k < (ns > 0 ? ns - 1 : 0) ? k : (ns > 0 ? ns - 1 : 0);
+  const bool walking = k >= 0 && k < ns;
+  const int kk = k < 0 ? 0 : k;
+  const int kc = kk < (ns > 0 ? ns - 1 : 0) ? kk : (ns > 0 ? ns - 1 : 0);
   const int sd = side[E * K + kc];
-  const int kr = k < ns ? k : ns;
+  const int kr = kk < ns ? kk : ns;
   const T *c = coef + (E * K + kc) * 16;
   const T pw[4] = {T(1), s, s * s, s * s * s}, d1[4] = {T(0), T(1), 2 * s, 3 * s * s}, d2[4] = {T(0), T(0), T(2), 6 * s};
   T pos[4], vel[4], acc[4];
@@ -147,8 +149,8 @@ __global__ __launch_bounds__(256) void k_walk(int n, const T *coef, const int *s
 #pragma unroll
   for (int f = 0; f < 2; f++) {
     const bool swing = walking && sd == f;
-    const T *rs = rest + ((E * (K + 1) + kr) * 2 + f) * 3;
-    const T x = swing ? pos[0] : rs[0], y = swing ? pos[1] : rs[1], z = swing ? pos[2] : T(0), yaw = swing ? pos[3] : rs[2];
+    const T *rs = rest + ((E * (K + 1) + kr) * 2 + f) * 4;
+    const T x = swing ? pos[0] : rs[0], y = swing ? pos[1] : rs[1], z = swing ? pos[2] : rs[3], yaw = swing ? pos[3] : rs[2];
     const T cy = cos(yaw), sy = sin(yaw);
     T smp[24] = {x, y, z, cy, sy, 0, -sy, cy, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (swing) {
@@ -173,12 +175,25 @@ __global__ __launch_bounds__(256) void k_walk(int n, const T *coef, const int *s
       for (int i = 0; i < 24; i++) fo[i] = smp[i];
     }
   }
-  // planar CoM target: midpoint of the feet, blended linearly over the step
-  const int k0 = kr, k1 = k0 + 1 < ns ? k0 + 1 : ns;
-  const T *r0 = rest + (E * (K + 1) + k0) * 6, *r1 = rest + (E * (K + 1) + k1) * 6;
-  const T a = s / Tstep;
-  com_ref[E * 9 + 0] = (1 - a) * T(0.5) * (r0[0] + r0[3]) + a * T(0.5) * (r1[0] + r1[3]);
-  com_ref[E * 9 + 1] = (1 - a) * T(0.5) * (r0[1] + r0[4]) + a * T(0.5) * (r1[1] + r1[4]);
+  // CoM reference: LIPM segment (zmp, d, c) of the current phase in the plane, quintic descent in height
+  const int ph = k + 1 < ns + 1 ? k + 1 : ns + 1;
+  const T sc = (k >= 0 && ph > ns) ? (t - t_start) - ns * Tstep : s;
+  const T ep = exp(omega * sc), em = exp(-omega * sc);
+#pragma unroll
+  for (int a = 0; a < 2; a++) {
+    const T *sg = com + ((E * (K + 2) + ph) * 2 + a) * 3;
+    const T u = T(0.5) * sg[1] * ep + sg[2] * em;
+    com_ref[E * 9 + a] = sg[0] + u;
+    com_ref[E * 9 + 3 + a] = omega * (T(0.5) * sg[1] * ep - sg[2] * em);
+    com_ref[E * 9 + 6 + a] = omega * omega * u;
+  }
+  const T a = t_start > 0 ? (t < t_start ? t / t_start : T(1)) : T(1);
+  const T sz = a * a * a * (10 - 15 * a + 6 * a * a);
+  const T dsz = t_start > 0 ? 30 * a * a * (1 - a) * (1 - a) / t_start : T(0);
+  const T ddsz = t_start > 0 ? 60 * a * (1 - a) * (1 - 2 * a) / (t_start * t_start) : T(0);
+  com_ref[E * 9 + 2] = z0 - dz * sz;
+  com_ref[E * 9 + 5] = -dz * dsz;
+  com_ref[E * 9 + 8] = -dz * ddsz;
 }
 
 // ============================================================================ host side
@@ -463,10 +478,10 @@ static void launch_tick(tsidb_ctx *h, void *q, void *v, void *tau, void *dv, voi
   HIP_OK(hipGetLastError());
 }
 template <typename T>
-static void launch_sim(tsidb_ctx *h, const void *q_tsid, void *qpos, void *qvel, void *qacc_ws, void *qacc, int32_t *ncon,
-                       int32_t *con, int32_t *info, hipStream_t s, const void *motor_tau = nullptr) {
+static void launch_sim(tsidb_ctx *h, const void *q_tsid, const void *v_tsid, void *qpos, void *qvel, void *qacc_ws, void *qacc,
+                       int32_t *ncon, int32_t *con, int32_t *info, hipStream_t s, const void *motor_tau = nullptr) {
   hipLaunchKernelGGL(k_sim<T>, dim3(h->num_envs), dim3(WAVE), 0, s, (const DevModel<T> *)h->d_model, h->num_envs,
-                     (const T *)q_tsid, (T *)qpos, (T *)qvel, (T *)qacc_ws, (const T *)h->env_params, (const T *)motor_tau, (T *)qacc, ncon, con, info);
+                     (const T *)q_tsid, (const T *)v_tsid, (T *)qpos, (T *)qvel, (T *)qacc_ws, (const T *)h->env_params, (const T *)motor_tau, (T *)qacc, ncon, con, info);
   HIP_OK(hipGetLastError());
 }
 
@@ -563,12 +578,12 @@ int tsidb_tick(tsidb_handle h, void *q, void *v, void *tau, void *dv, void *f, i
   GUARD_END
 }
 
-int tsidb_sim(tsidb_handle h, const void *q_tsid, void *qpos, void *qvel, void *qacc_ws, void *qacc, int32_t *ncon,
-              int32_t *con_pairs, int32_t *info, void *stream) {
+int tsidb_sim(tsidb_handle h, const void *q_tsid, const void *v_tsid, void *qpos, void *qvel, void *qacc_ws, void *qacc,
+              int32_t *ncon, int32_t *con_pairs, int32_t *info, void *stream) {
   GUARD_BEGIN
   if (!qpos || !qvel || !qacc_ws) throw std::string("tsidb_sim: null state buffer");
-  if (h->dtype == TSIDB_F64) launch_sim<double>(h, q_tsid, qpos, qvel, qacc_ws, qacc, ncon, con_pairs, info, (hipStream_t)stream);
-  else launch_sim<float>(h, q_tsid, qpos, qvel, qacc_ws, qacc, ncon, con_pairs, info, (hipStream_t)stream);
+  if (h->dtype == TSIDB_F64) launch_sim<double>(h, q_tsid, v_tsid, qpos, qvel, qacc_ws, qacc, ncon, con_pairs, info, (hipStream_t)stream);
+  else launch_sim<float>(h, q_tsid, v_tsid, qpos, qvel, qacc_ws, qacc, ncon, con_pairs, info, (hipStream_t)stream);
   GUARD_END
 }
 
@@ -585,30 +600,34 @@ int tsidb_step(tsidb_handle h, void *q, void *v, void *qpos, void *qvel, void *q
     // closed loop: the tick reads the sim state, the sim is driven by tau and keeps its own base pose
     if (h->dtype == TSIDB_F64) {
       launch_tick<double>(h, q, v, tau, dv, f, status, obs, frames, info, s, closed ? qpos : nullptr, closed ? qvel : nullptr);
-      if (sim) launch_sim<double>(h, closed ? nullptr : q, qpos, qvel, qacc_ws, nullptr, ncon, con_pairs, info, s, closed ? tau : nullptr);
+      if (sim) launch_sim<double>(h, closed ? nullptr : q, closed ? nullptr : v, qpos, qvel, qacc_ws, nullptr, ncon, con_pairs, info, s, closed ? tau : nullptr);
     } else {
       launch_tick<float>(h, q, v, tau, dv, f, status, obs, frames, info, s, closed ? qpos : nullptr, closed ? qvel : nullptr);
-      if (sim) launch_sim<float>(h, closed ? nullptr : q, qpos, qvel, qacc_ws, nullptr, ncon, con_pairs, info, s, closed ? tau : nullptr);
+      if (sim) launch_sim<float>(h, closed ? nullptr : q, closed ? nullptr : v, qpos, qvel, qacc_ws, nullptr, ncon, con_pairs, info, s, closed ? tau : nullptr);
     }
   }
   GUARD_END
 }
 
-int tsidb_walk_update(tsidb_handle h, const void *coef, const int32_t *side, const int32_t *nsteps, const void *rest, int K,
-                      double t, double step_duration, const void *frames, void *stream) {
+int tsidb_walk_update(tsidb_handle h, const void *coef, const int32_t *side, const int32_t *nsteps, const void *rest,
+                      const void *com, int K, double t, double step_duration, double t_start, double omega, double com_z0,
+                      double com_drop, const void *frames, void *stream) {
   GUARD_BEGIN
   need_refs(h);
-  if (!coef || !side || !nsteps || !rest || !frames || K <= 0) throw std::string("tsidb_walk_update: null table or K <= 0");
+  if (!coef || !side || !nsteps || !rest || !com || !frames || K <= 0) throw std::string("tsidb_walk_update: null table or K <= 0");
+  if (!(step_duration > 0) || !(omega > 0) || t_start < 0) throw std::string("tsidb_walk_update: bad timing");
   hipStream_t s = (hipStream_t)stream;
   const int grid = (h->num_envs + 255) / 256;
   if (h->dtype == TSIDB_F64)
     hipLaunchKernelGGL(k_walk<double>, dim3(grid), dim3(256), 0, s, h->num_envs, (const double *)coef, side, nsteps,
-                       (const double *)rest, K, t, step_duration, (const double *)frames, (double *)h->foot_ref,
-                       (double *)h->contact_ref, (uint8_t *)h->contact_active, (double *)h->com_ref);
+                       (const double *)rest, (const double *)com, K, t, step_duration, t_start, omega, com_z0, com_drop,
+                       (const double *)frames, (double *)h->foot_ref, (double *)h->contact_ref, (uint8_t *)h->contact_active,
+                       (double *)h->com_ref);
   else
     hipLaunchKernelGGL(k_walk<float>, dim3(grid), dim3(256), 0, s, h->num_envs, (const float *)coef, side, nsteps,
-                       (const float *)rest, K, (float)t, (float)step_duration, (const float *)frames, (float *)h->foot_ref,
-                       (float *)h->contact_ref, (uint8_t *)h->contact_active, (float *)h->com_ref);
+                       (const float *)rest, (const float *)com, K, (float)t, (float)step_duration, (float)t_start, (float)omega,
+                       (float)com_z0, (float)com_drop, (const float *)frames, (float *)h->foot_ref, (float *)h->contact_ref,
+                       (uint8_t *)h->contact_active, (float *)h->com_ref);
   HIP_OK(hipGetLastError());
   GUARD_END
 }

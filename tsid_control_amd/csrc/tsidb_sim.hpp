@@ -160,7 +160,7 @@ __device__ __forceinline__ void rows_eval(const RowState<T> &rs, T alpha, T &c, 
 }
 
 template <typename T>
-__device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L, int lane, const T *q_tsid, T *qpos_g, T *qvel_g,
+__device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L, int lane, const T *q_tsid, const T *v_tsid, T *qpos_g, T *qvel_g,
                              T *qacc_ws_g, const T *envp, const T *motor_tau, T *qacc_out, int *ncon_out, int *con_out,
                              int *info) {
   // per-env randomisation (BASELINE config 5), NULL = nominal: mass scale, contact friction, floor plane
@@ -197,7 +197,24 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
     }
     L.qpos[lane] = val;
   }
-  if (lane < NV) L.qvel[lane] = qvel_g[lane];
+  if (lane < NV) {
+    T val = qvel_g[lane];
+    if (q_tsid && v_tsid && !quirks && lane < 6) {
+      // the base is kinematic in this mode: its velocity comes with its pose (the reference writes
+      // qpos[:7] only, main.py:192, which is harmless only while the robot stands still).  TSID: linear
+      // and angular velocity in the body frame; sim: linear in the world frame, angular in the body frame.
+      if (lane < 3) {
+        const T x = q_tsid[3], y = q_tsid[4], z = q_tsid[5], w = q_tsid[6];
+        const T r0 = lane == 0 ? 1 - 2 * (y * y + z * z) : lane == 1 ? 2 * (x * y + w * z) : 2 * (x * z - w * y);
+        const T r1 = lane == 0 ? 2 * (x * y - w * z) : lane == 1 ? 1 - 2 * (x * x + z * z) : 2 * (y * z + w * x);
+        const T r2 = lane == 0 ? 2 * (x * z + w * y) : lane == 1 ? 2 * (y * z - w * x) : 1 - 2 * (x * x + y * y);
+        val = r0 * v_tsid[0] + r1 * v_tsid[1] + r2 * v_tsid[2];
+      } else {
+        val = v_tsid[lane];
+      }
+    }
+    L.qvel[lane] = val;
+  }
   const T myctrl = (lane < NA && q_tsid) ? q_tsid[m.mj_ctrl_qidx[lane]] : T(0); // joint target of actuator `lane`
   for (int i = lane; i < NV * LDM; i += WAVE) L.M[i] = 0;
   __syncthreads();

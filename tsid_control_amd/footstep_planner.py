@@ -104,3 +104,15 @@ def unicycle_path(v=0.5, w=0.1, dt=0.1, n=100, scale=1.0):
         th += w * dt
         pts.append(np.array([x, y]) * scale)
     return pts
+
+
+def resample_path(path, ds):
+    """Polyline with vertices at most `ds` apart (linear interpolation).  FootstepPlanner.plan emits a
+    step at the first vertex past each step_length of travel, so the vertex spacing quantises the stride;
+    the demo path's 5 cm spacing is as long as an OP3 step."""
+    pts = [np.asarray(path[0], dtype=np.float64)]
+    for a, b in zip(path[:-1], path[1:]):
+        a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+        m = max(1, int(np.ceil(np.linalg.norm(b - a) / ds)))
+        pts.extend(a + (b - a) * (i / m) for i in range(1, m + 1))
+    return pts

@@ -188,13 +188,16 @@ class WalkController:
         _lib.check(self._L, self._h, rc, "tsidb_tick")
         return self.tau, self.q, self.v, self.status, self.obs
 
-    def sim_step(self, teleport=True, q_tsid=None):
-        """Sim stage only (main.py:192-195); teleport=False steps the sim state on its own; q_tsid
-        overrides the TSID state the base pose / joint targets are taken from (a snapshot of self.q when
-        the sim stage runs on another stream than the tick)."""
+    def sim_step(self, teleport=True, q_tsid=None, v_tsid=None):
+        """Sim stage only (main.py:192-195); teleport=False steps the sim state on its own; q_tsid / v_tsid
+        override the TSID state the base pose / joint targets (and, with reference_quirks=False, the base
+        velocity) are taken from (snapshots of self.q / self.v when the sim stage runs on another stream
+        than the tick)."""
         src = q_tsid if q_tsid is not None else self.q
+        srcv = v_tsid if v_tsid is not None else self.v
         with torch.cuda.device(self.device):
-            rc = self._L.tsidb_sim(self._h, _ptr(src) if teleport else None, _ptr(self.qpos), _ptr(self.qvel),
+            rc = self._L.tsidb_sim(self._h, _ptr(src) if teleport else None, _ptr(srcv) if teleport else None,
+                                   _ptr(self.qpos), _ptr(self.qvel),
                                    _ptr(self.qacc_warmstart), None, _ptr(self.ncon), _ptr(self.con_pairs),
                                    _ptr(self.info), self._stream())
         _lib.check(self._L, self._h, rc, "tsidb_sim")

@@ -15,7 +15,7 @@ import torch
 
 from .conf import RobotConfig
 from .foot_trajectory import FootTrajectory
-from .footstep_planner import Footstep, FootstepPlanner, unicycle_path
+from .footstep_planner import Footstep, FootstepPlanner, resample_path, unicycle_path
 
 
 class WalkPlanner:
@@ -36,69 +36,163 @@ class WalkPlanner:
         return swings
 
 
-class WalkSchedule:
-    """Per-env swing tables: coef [N, K, 4, 4] (x, y, z, yaw polynomials in time since step start),
-    side [N, K] (0 = left foot swings), nsteps [N]; foot rest poses before/after each step."""
+def op3_walking_conf(conf: RobotConfig = None) -> RobotConfig:
+    """Config-3 walking workload sized for the OP3.  The reference's step parameters (conf.py:24-28:
+    0.3 m steps, 0.2 m apart and 0.2 m high) belong to a robot several times the OP3's size (leg length
+    0.22 m, feet 0.085 m apart), and its task weights (conf.py:47-60, posture as heavy as the feet and the
+    CoM) hold the standing posture - with them the TSID state does not follow a footstep plan at all and
+    diverges after ~2500 ticks (tools/walk_trace.py reproduces it on the CPU).  The reference never ran
+    its walking branch (main.py:117 is commented out), so these are the build's own values,
+    in the proportions of tsid's biped walking example: tracking tasks dominate, posture regularises."""
+    c = conf or RobotConfig()
+    c.step_length, c.step_width, c.step_height, c.step_duration, c.rise_ratio = 0.05, 0.085, 0.03, 0.5, 0.5
+    c.w_com, c.w_foot, c.w_posture = 1.0, 1.0, 1e-3
+    c.kp_com, c.kp_foot = 20.0, 100.0
+    # the reference's swing trajectories touch down at 4 h / T = 0.24 m/s (a parabola in z, a straight line in
+    # x and y); with kp_contact = 10 the re-referenced contact overshoots by centimetres before it stops
+    c.kp_contact = 900.0
+    return c
 
-    def __init__(self, plans: List[List[Footstep]], conf: RobotConfig, device, dtype):
+
+def op3_walking_posture(bend=0.45):
+    """Posture-task reference for walking: knees bent by 2*bend with the feet kept flat under the hips
+    (TSID joint order: left leg hip pitch / knee / ankle pitch = joints 4, 5, 6, right leg 13, 14, 15; the
+    ankle axes point the other way).  The SRDF standing pose (robot.srdf:5-25) has the legs straight, which
+    is singular for lowering the hips; bend = 0.45 rad lowers them by 0.22 (1 - cos bend) = 2.2 cm."""
+    p = np.zeros(20)
+    p[4], p[5], p[6] = bend, -2.0 * bend, -bend
+    p[13], p[14], p[15] = -bend, 2.0 * bend, bend
+    return p
+
+
+class WalkSchedule:
+    """Per-env walking tables, evaluated each tick on the device (no host round trip).
+
+    Timeline: [0, t_start) both feet down, the CoM sinks by com_drop and the divergent component of
+    motion (DCM) is brought to the first step's start value; step k occupies
+    [t_start + k T, t_start + (k+1) T) in single support on the foot the plan put down last; after the
+    last step both feet are down again.
+
+      coef  [N, K, 4, 4]   swing polynomials x, y, z, yaw in time since step start (a12)
+      side  [N, K]         0 = left foot swings;  nsteps [N]
+      rest  [N, K+1, 2, 4] (x, y, yaw, z) of [left, right] foot before step k
+      com   [N, K+2, 2, 3] LIPM segment (zmp, d, c) per planar axis for phase 0 (start), 1..ns (steps),
+                           ns+1 (final stand):  x(s) = zmp + d/2 e^{w s} + c e^{-w s}  (a13; the closed
+                           form of LIPM.py:44-49's recurrence about a fixed ZMP), s = time in the phase.
+    Yaw is relative to the robot's initial heading."""
+
+    def __init__(self, plans: List[List[Footstep]], conf: RobotConfig, device, dtype, com0=None, heading=0.0,
+                 t_start=1.0, com_drop=0.015, foot_press=0.002):
+        """foot_press: every swing is aimed this far below the height the foot started the episode at, so
+        that the slave sim (base teleported to the TSID pose each step, main.py:192) finds the stance foot
+        pressed into the floor instead of hovering a tracking error above it."""
         self.conf = conf
         N = len(plans)
         K = max(len(p) - 2 for p in plans)
+        T = conf.step_duration
+        com0 = np.asarray(com0 if com0 is not None else [0.0, 0.0, 0.24], dtype=np.float64)
+        self.z0, self.dz, self.t_start = float(com0[2]), float(com_drop), float(t_start)
+        self.omega = float(np.sqrt(9.80665 / (self.z0 - self.dz)))  # LIPM.py:15
+        w = self.omega
         coef = np.zeros((N, K, 4, 4))
         side = np.zeros((N, K), dtype=np.int64)
         nsteps = np.zeros(N, dtype=np.int64)
-        rest = np.zeros((N, K + 1, 2, 3))  # (x, y, yaw) of [left, right] foot before step k
-        wp = WalkPlanner(conf)
+        rest = np.zeros((N, K + 1, 2, 4))
+        com = np.zeros((N, K + 2, 2, 3))
+        done = {}
         for e, steps in enumerate(plans):
-            swings = wp.plan(steps)
-            nsteps[e] = len(swings)
+            if id(steps) in done:  # envs sharing a plan share its tables
+                s = done[id(steps)]
+                coef[e], side[e], nsteps[e], rest[e], com[e] = coef[s], side[s], nsteps[s], rest[s], com[s]
+                continue
+            done[id(steps)] = e
+            ns = nsteps[e] = max(len(steps) - 2, 0)
             cur = {}
             for s in steps[:2]:
-                cur[int(bool(s.side))] = np.array([s.position[0], s.position[1], s.orientation[2]])
+                cur[int(bool(s.side))] = np.array([s.position[0], s.position[1], s.orientation[2] - heading, 0.0])
             for k in range(K + 1):
                 rest[e, k, 0], rest[e, k, 1] = cur[0], cur[1]
-                if k < len(swings):
-                    coef[e, k] = swings[k].coefficients()
+                if k < ns:
+                    # swing from footstep k to footstep k+2 (Walk_Planner.py:23-31)
                     sd = int(bool(steps[k].side))
-                    side[e, k] = sd
                     tgt = steps[k + 2]
-                    cur[sd] = np.array([tgt.position[0], tgt.position[1], tgt.orientation[2]])
+                    nxt = np.array([tgt.position[0], tgt.position[1], tgt.orientation[2] - heading, -foot_press])
+                    c0 = cur[sd]
+                    coef[e, k] = FootTrajectory([0.0, T], start=[c0[0], c0[1], c0[3], c0[2]], target=[nxt[0], nxt[1], nxt[3], nxt[2]],
+                                                step_height=conf.step_height, rise_ratio=conf.rise_ratio).coefficients()
+                    side[e, k] = sd
+                    cur[sd] = nxt
+            # DCM end points backwards from the final stand (ZMP of step k = the stance foot = steps[k+1])
+            final = 0.5 * (steps[ns].position + steps[ns + 1].position) if ns > 0 else com0[:2]
+            xi = np.zeros((ns + 1, 2))
+            xi[ns] = final
+            for k in range(ns - 1, -1, -1):
+                z = steps[k + 1].position
+                xi[k] = z + (xi[k + 1] - z) * np.exp(-w * T)
+            # phase 0: constant ZMP that carries the DCM from the initial CoM to xi[0] in t_start
+            x = com0[:2].copy()
+            E0 = np.exp(w * t_start)
+            z = (xi[0] - x * E0) / (1.0 - E0)
+            d, c = x - z, (x - z) - 0.5 * (x - z)
+            com[e, 0, :, 0], com[e, 0, :, 1], com[e, 0, :, 2] = z, d, c
+            x = z + 0.5 * d * E0 + c / E0
+            for k in range(ns):
+                z = steps[k + 1].position
+                d = xi[k] - z
+                c = (x - z) - 0.5 * d
+                com[e, k + 1, :, 0], com[e, k + 1, :, 1], com[e, k + 1, :, 2] = z, d, c
+                x = z + 0.5 * d * np.exp(w * T) + c * np.exp(-w * T)
+            com[e, ns + 1:, :, 0] = final
+            com[e, ns + 1:, :, 2] = x - final
         t = lambda a, dt=dtype: torch.as_tensor(a, device=device).to(dt)
-        self.coef, self.rest = t(coef), t(rest)
+        self.coef, self.rest, self.com = t(coef), t(rest), t(com)
         self.side, self.nsteps = t(side, torch.long), t(nsteps, torch.long)
         self.N, self.K = N, K
         self.device, self.dtype = device, dtype
 
     @classmethod
-    def from_demo_paths(cls, num_envs, conf: RobotConfig, device, dtype, seed=1, q0_feet=None):
+    def from_demo_paths(cls, num_envs, conf: RobotConfig, device, dtype, seed=1, q0_feet=None, com0=None, **kw):
         """Config-3 workload: the reference's demo unicycle path
-        (Footstep_Planner.py:131-141) scaled per env by U(0.5, 1.0)."""
+        (Footstep_Planner.py:131-141) scaled per env by U(0.5, 1.0), turned into the robot's initial
+        heading (the direction the left foot is to the left of) and started between its feet."""
         rng = np.random.default_rng(seed)
         planner = FootstepPlanner(conf.step_width, conf.step_length)
-        lf = q0_feet[0] if q0_feet is not None else np.array([0.0, 0.1])
-        rf = q0_feet[1] if q0_feet is not None else np.array([0.0, -0.1])
+        lf = np.asarray(q0_feet[0] if q0_feet is not None else [0.0, 0.1], dtype=np.float64)
+        rf = np.asarray(q0_feet[1] if q0_feet is not None else [0.0, -0.1], dtype=np.float64)
+        left = lf - rf
+        heading = float(np.arctan2(-left[0], left[1]))
+        ch, sh = np.cos(heading), np.sin(heading)
+        Rh = np.array([[ch, -sh], [sh, ch]])
         plans = []
         scales = rng.uniform(0.5, 1.0, size=num_envs)
         cache = {}
         for sc in scales:
             key = round(float(sc), 2)  # 51 distinct paths keep the host-side planning cheap
             if key not in cache:
-                path = [p + 0.5 * (lf + rf) for p in unicycle_path(scale=key)]
-                init = [Footstep(lf, np.zeros(3), 0), Footstep(rf, np.zeros(3), 1)]
+                path = resample_path([Rh @ p + 0.5 * (lf + rf) for p in unicycle_path(scale=key)], conf.step_length / 10)
+                init = [Footstep(lf, np.array([0.0, 0.0, heading]), 0), Footstep(rf, np.array([0.0, 0.0, heading]), 1)]
                 cache[key] = planner.plan(path, init)
             plans.append(cache[key])
-        return cls(plans, conf, device, dtype)
+        if com0 is None:
+            com0 = np.array([*(0.5 * (lf + rf)), 0.24])
+        return cls(plans, conf, device, dtype, com0=com0, heading=heading, **kw)
+
+    def _phase(self, t: float):
+        """(step index k, time in the step) for t >= t_start; k = -1 before the first step."""
+        T = self.conf.step_duration
+        if t < self.t_start:
+            return -1, t
+        k = int(np.floor((t - self.t_start) / T))
+        return k, (t - self.t_start) - k * T
 
     def sample(self, t: float):
         """Foot-task samples and contact flags at time t: (sampleLF [N,24], sampleRF [N,24],
         contact_LF [N] bool, contact_RF [N] bool).  Sample layout = tsid SE3 TrajectorySample:
         p(3), R column-major(9), v(6), a(6), twists world-aligned."""
-        T = self.conf.step_duration
-        k = int(np.floor(t / T))
-        s = t - k * T
+        k, s = self._phase(t)
         N = self.N
-        kk = torch.full((N,), k, dtype=torch.long, device=self.device)
-        walking = kk < self.nsteps
+        kk = torch.full((N,), max(k, 0), dtype=torch.long, device=self.device)
+        walking = (kk < self.nsteps) & (k >= 0)
         kc = torch.minimum(kk, torch.clamp(self.nsteps - 1, min=0))
         ar = torch.arange(N, device=self.device)
         c = self.coef[ar, kc]                         # [N,4,4]
@@ -107,13 +201,13 @@ class WalkSchedule:
         d2 = torch.tensor([0.0, 0.0, 2.0, 6 * s], dtype=self.dtype, device=self.device)
         pos, vel, acc = c @ pw, c @ d1, c @ d2        # [N,4] x y z yaw
         sd = self.side[ar, kc]
-        rest = self.rest[ar, torch.minimum(kk, self.nsteps)]  # [N,2,3]
+        rest = self.rest[ar, torch.minimum(kk, self.nsteps)]  # [N,2,4]
         out = []
         for f in (0, 1):
             swing = walking & (sd == f)
             x = torch.where(swing, pos[:, 0], rest[:, f, 0])
             y = torch.where(swing, pos[:, 1], rest[:, f, 1])
-            z = torch.where(swing, pos[:, 2], torch.zeros_like(x))
+            z = torch.where(swing, pos[:, 2], rest[:, f, 3])
             yaw = torch.where(swing, pos[:, 3], rest[:, f, 2])
             cy, sy = torch.cos(yaw), torch.sin(yaw)
             zero, one = torch.zeros_like(x), torch.ones_like(x)
@@ -124,30 +218,46 @@ class WalkSchedule:
             out.append((torch.cat([torch.stack([x, y, z], dim=-1), Rcm, v6, a6], dim=-1), ~swing))
         return out[0][0], out[1][0], out[0][1], out[1][1]
 
+    def com_ref(self, t: float):
+        """CoM task reference [N, 9] = position, velocity, acceleration: LIPM segments in the plane,
+        a quintic descent by com_drop during [0, t_start) in height."""
+        k, s = self._phase(t)
+        ph = torch.minimum(torch.full((self.N,), k + 1, dtype=torch.long, device=self.device), self.nsteps + 1)
+        T = self.conf.step_duration
+        # time inside the final stand keeps running from the end of the last step
+        s_t = torch.where(ph > self.nsteps, (t - self.t_start) - self.nsteps.to(self.dtype) * T,
+                          torch.full((self.N,), s, dtype=self.dtype, device=self.device)) if k >= 0 else \
+            torch.full((self.N,), s, dtype=self.dtype, device=self.device)
+        seg = self.com[torch.arange(self.N, device=self.device), ph]  # [N,2,3]
+        w = self.omega
+        ep, em = torch.exp(w * s_t)[:, None], torch.exp(-w * s_t)[:, None]
+        u = 0.5 * seg[:, :, 1] * ep + seg[:, :, 2] * em
+        pos = seg[:, :, 0] + u
+        vel = w * (0.5 * seg[:, :, 1] * ep - seg[:, :, 2] * em)
+        acc = w * w * u
+        a = min(t / self.t_start, 1.0) if self.t_start > 0 else 1.0
+        sz = a * a * a * (10 - 15 * a + 6 * a * a)
+        dsz = 30 * a * a * (1 - a) ** 2 / self.t_start if self.t_start > 0 else 0.0
+        ddsz = 60 * a * (1 - a) * (1 - 2 * a) / self.t_start ** 2 if self.t_start > 0 else 0.0
+        out = torch.zeros(self.N, 9, dtype=self.dtype, device=self.device)
+        out[:, 0:2], out[:, 3:5], out[:, 6:8] = pos, vel, acc
+        out[:, 2], out[:, 5], out[:, 8] = self.z0 - self.dz * sz, -self.dz * dsz, -self.dz * ddsz
+        return out
+
     def apply(self, wc, t: float):
-        """Device path of one tick's reference update: foot samples, contact switching and the planar
-        CoM target for every env in one kernel (tsidb_walk_update); equivalent to
-        wc.update_tasks(*self.sample(t)) followed by wc.com_ref[:, :2] = self.com_xy(t)."""
+        """Device path of one tick's reference update: foot samples, contact switching and the CoM
+        reference for every env in one kernel (tsidb_walk_update); equivalent to
+        wc.update_tasks(*self.sample(t)) followed by wc.com_ref[:] = self.com_ref(t)."""
         import ctypes as C
         from . import _lib
         if not hasattr(self, "_side32"):
             self._side32 = self.side.to(torch.int32).contiguous()
             self._nsteps32 = self.nsteps.to(torch.int32).contiguous()
-            self._coef_c, self._rest_c = self.coef.contiguous(), self.rest.contiguous()
+            self._coef_c, self._rest_c, self._com_c = self.coef.contiguous(), self.rest.contiguous(), self.com.contiguous()
         p = lambda x: C.c_void_p(x.data_ptr())
         with torch.cuda.device(wc.device):
-            rc = wc._L.tsidb_walk_update(wc._h, p(self._coef_c), p(self._side32), p(self._nsteps32), p(self._rest_c), self.K,
-                                         float(t), float(self.conf.step_duration), p(wc.frames), wc._stream())
+            rc = wc._L.tsidb_walk_update(wc._h, p(self._coef_c), p(self._side32), p(self._nsteps32), p(self._rest_c),
+                                         p(self._com_c), self.K, float(t), float(self.conf.step_duration),
+                                         float(self.t_start), float(self.omega), float(self.z0), float(self.dz),
+                                         p(wc.frames), wc._stream())
         _lib.check(wc._L, wc._h, rc, "tsidb_walk_update")
-
-    def com_xy(self, t: float):
-        """Planar CoM target: midpoint of the two foot targets, blended linearly over the step."""
-        T = self.conf.step_duration
-        k = int(np.floor(t / T))
-        a = (t - k * T) / T
-        ar = torch.arange(self.N, device=self.device)
-        k0 = torch.minimum(torch.full((self.N,), k, dtype=torch.long, device=self.device), self.nsteps)
-        k1 = torch.minimum(k0 + 1, self.nsteps)
-        m0 = self.rest[ar, k0][:, :, :2].mean(dim=1)
-        m1 = self.rest[ar, k1][:, :, :2].mean(dim=1)
-        return (1 - a) * m0 + a * m1
