@@ -39,8 +39,11 @@ NOMINAL_FLOP_PER_ENV_STEP = 0.5e6  # SURVEY.md 8(d), structure-exploiting estima
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=5000, help="timed steps; 5000 ticks = the 10 s of SURVEY.md 8(d) cfg 3")
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--preroll", type=int, default=600,
+                    help="walk workload only: untimed steps of state initialisation before the warm-up, so that the "
+                         "timed window starts in steady walking (the plan's first second is a double-support start)")
     ap.add_argument("--envs-per-gpu", type=int, default=4096)
     ap.add_argument("--dtype", choices=["f64", "f32"], default="f64")
     ap.add_argument("--workload", choices=["walk", "stand"], default="walk")
@@ -176,14 +179,15 @@ def main():
         gather(wc.obs)
 
     failed_any = torch.zeros(n, dtype=torch.bool, device=dev)
-    for i in range(args.warmup):
+    pre = args.preroll if args.workload == "walk" else 0
+    for i in range(pre + args.warmup):
         one_step(i)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(args.steps):
-        one_step(args.warmup + k, k)
+        one_step(pre + args.warmup + k, k)
         if k % 64 == 63:
             failed_any |= wc.status != 0   # sampled every 64th step: one tiny kernel, not per step
     torch.cuda.synchronize()
@@ -229,7 +233,7 @@ def main():
                                     "reference + swing trajectories -> update_tasks each tick; TSID tick + sim step)"
                                     if args.workload == "walk" else
                                     "cfg2: perturbed stand/balance per GPU"),
-                       "envs_per_gpu": n, "global_envs": n * world, "parallelism": f"env-sharded x{world}, obs all-gather",
+                       "envs_per_gpu": n, "global_envs": n * world, "preroll_steps": pre, "parallelism": f"env-sharded x{world}, obs all-gather",
                        "streams": "sim(t) overlapped with tick(t+1) on a second HIP stream" if overlap else "single stream",
                        "qp_failed_envs_last_step": n_bad, "last_step_stats": stats},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

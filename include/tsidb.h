@@ -34,6 +34,7 @@ enum {
   TSIDB_P_CPOINTS = TSIDB_P_NORMAL + 3 /*4x3*/, TSIDB_P_KP_POSTURE = TSIDB_P_CPOINTS + 12 /*20*/,
   TSIDB_P_KD_POSTURE = TSIDB_P_KP_POSTURE + 20, TSIDB_P_TAU_MAX = TSIDB_P_KD_POSTURE + 20,
   TSIDB_P_V_MAX = TSIDB_P_TAU_MAX + 20, TSIDB_P_MAX_ITER = TSIDB_P_V_MAX + 20, TSIDB_P_SIM_ENABLED, TSIDB_P_CLOSED_LOOP,
+  TSIDB_P_W_AM /* angular-momentum task weight (legacy/biped.py:82-87), 0 = not in the stack */, TSIDB_P_KP_AM /*3*/,
   TSIDB_P_COUNT = 128
 };
 

@@ -284,6 +284,58 @@ void or_rbd_terms(const OrModel *m, const double *q, const double *v, OrTerms *t
     }
   }
 
+  /* ---- centroidal angular momentum, body by body (independent of the composite recursion above):
+   *      L_G = sum_j I_j w_j + m_j (c_j - C) x v_cj ; column `col` of A_G takes the unit motion of dof col */
+  for (int j = 0; j < OR_NJ; j++) {
+    const double *Y = m->pin_inertia[j];
+    const double *R = k.oMi[j].R;
+    double cw[3], Il[9] = {Y[4], Y[5], Y[6], Y[5], Y[7], Y[8], Y[6], Y[8], Y[9]}, Iw[9], tmp9[9];
+    matvec(R, Y + 1, cw);
+    for (int i = 0; i < 3; i++) cw[i] += k.oMi[j].p[i];
+    for (int r = 0; r < 3; r++)
+      for (int c = 0; c < 3; c++) {
+        tmp9[3 * r + c] = 0;
+        for (int e = 0; e < 3; e++) tmp9[3 * r + c] += R[3 * r + e] * Il[3 * e + c];
+      }
+    for (int r = 0; r < 3; r++)
+      for (int c = 0; c < 3; c++) {
+        Iw[3 * r + c] = 0;
+        for (int e = 0; e < 3; e++) Iw[3 * r + c] += tmp9[3 * r + e] * R[3 * c + e];
+      }
+    double rc[3] = {cw[0] - t->com[0], cw[1] - t->com[1], cw[2] - t->com[2]};
+    for (int a = j;; a = m->pin_parent[a]) {
+      int nd = a == 0 ? 6 : 1;
+      for (int d = 0; d < nd; d++) {
+        int col = dof_of(a) + d;
+        double wxc[3], vc[3], Iw_w[3], rxv[3];
+        cross(Jw[col] + 3, cw, wxc);
+        for (int i = 0; i < 3; i++) vc[i] = Jw[col][i] + wxc[i];
+        matvec(Iw, Jw[col] + 3, Iw_w);
+        cross(rc, vc, rxv);
+        for (int i = 0; i < 3; i++) t->Aam[i][col] += Iw_w[i] + Y[0] * rxv[i];
+      }
+      if (a == 0) break;
+    }
+    /* drift: I alpha + w x I w + m (c - C) x a_c  with zero joint accelerations */
+    double ww[3], aw[3], vl[3], al[3], tmp[3], acw[3], Iw_a[3], Iw_w2[3], wxIw[3], rxa[3];
+    matvec(R, k.v[j] + 3, ww);
+    matvec(R, k.a[j] + 3, aw);
+    cross(k.v[j] + 3, Y + 1, tmp);
+    for (int i = 0; i < 3; i++) vl[i] = k.v[j][i] + tmp[i];
+    cross(k.a[j] + 3, Y + 1, tmp);
+    for (int i = 0; i < 3; i++) al[i] = k.a[j][i] + tmp[i];
+    cross(k.v[j] + 3, vl, tmp);
+    for (int i = 0; i < 3; i++) al[i] += tmp[i];
+    matvec(R, al, acw);
+    matvec(Iw, aw, Iw_a);
+    matvec(Iw, ww, Iw_w2);
+    cross(ww, Iw_w2, wxIw);
+    cross(rc, acw, rxa);
+    for (int i = 0; i < 3; i++) t->dLam[i] += Iw_a[i] + wxIw[i] + Y[0] * rxa[i];
+  }
+  for (int i = 0; i < 3; i++)
+    for (int c = 0; c < OR_NV; c++) t->Lam[i] += t->Aam[i][c] * v[c];
+
   /* ---- frames */
   for (int f = 0; f < OR_NF; f++) {
     int pj = m->frame_parent[f];

@@ -198,6 +198,15 @@ void or_tsid_assemble(const OrModel *m, const double *params, const OrTerms *t, 
     }
     ACCUM(3, params[P_W_COM]);
   }
+  if (params[P_W_AM] != 0.0) { /* angular momentum (legacy/biped.py:82-87; tsid::TaskAMEquality with a zero reference):
+                                * A_G,ang dv = -Kp L - drift.  setKd is stored and never used by the task. */
+    memset(A, 0, sizeof A);
+    for (int r = 0; r < 3; r++) {
+      for (int c = 0; c < OR_NV; c++) A[r][c] = t->Aam[r][c];
+      a[r] = -params[P_KP_AM + r] * t->Lam[r] - t->dLam[r];
+    }
+    ACCUM(3, params[P_W_AM]);
+  }
   { /* posture */
     memset(A, 0, sizeof A);
     for (int r = 0; r < OR_NA; r++) {

@@ -29,7 +29,7 @@ enum {
   P_HESS_REG, P_QUIRKS, P_NORMAL /*3*/, P_CPOINTS = P_NORMAL + 3 /*12*/,
   P_KP_POSTURE = P_CPOINTS + 12 /*20*/, P_KD_POSTURE = P_KP_POSTURE + 20,
   P_TAU_MAX = P_KD_POSTURE + 20, P_V_MAX = P_TAU_MAX + 20, P_MAX_ITER = P_V_MAX + 20,
-  P_SIM_ENABLED, P_CLOSED_LOOP, P_COUNT = 128
+  P_SIM_ENABLED, P_CLOSED_LOOP, P_W_AM, P_KP_AM /*3*/, P_COUNT = 128
 };
 
 typedef struct {
@@ -67,6 +67,9 @@ typedef struct {
   double Jf[OR_NF][6][OR_NV];     /* frame Jacobian, LOCAL */
   double vf[OR_NF][6], af[OR_NF][6]; /* frame velocity, classical drift acceleration (LOCAL) */
   double mass;
+  /* centroidal angular momentum (tsid::TaskAMEquality, legacy/biped.py:82-87): A_G angular rows, L = A v,
+   * drift = dA/dt v (what computeCentroidalMomentumTimeVariation leaves at zero joint acceleration) */
+  double Aam[3][OR_NV], Lam[3], dLam[3];
 } OrTerms;
 
 typedef struct {

@@ -17,7 +17,8 @@ class OrTerms(C.Structure):
     _fields_ = [("M", C.c_double * (NV * NV)), ("h", C.c_double * NV), ("com", C.c_double * 3),
                 ("vcom", C.c_double * 3), ("acom", C.c_double * 3), ("Jcom", C.c_double * (3 * NV)),
                 ("oMf", C.c_double * 24), ("Jf", C.c_double * (2 * 6 * NV)), ("vf", C.c_double * 12),
-                ("af", C.c_double * 12), ("mass", C.c_double)]
+                ("af", C.c_double * 12), ("mass", C.c_double), ("Aam", C.c_double * (3 * NV)), ("Lam", C.c_double * 3),
+                ("dLam", C.c_double * 3)]
 
 
 class OrQP(C.Structure):
@@ -87,7 +88,7 @@ class Oracle:
         g = lambda f, *s: np.array(f, dtype=np.float64).reshape(*s)
         return dict(M=g(t.M, NV, NV), h=g(t.h, NV), com=g(t.com, 3), vcom=g(t.vcom, 3), acom=g(t.acom, 3),
                     Jcom=g(t.Jcom, 3, NV), oMf=g(t.oMf, 2, 12), Jf=g(t.Jf, 2, 6, NV), vf=g(t.vf, 2, 6),
-                    af=g(t.af, 2, 6), mass=t.mass, _raw=t)
+                    af=g(t.af, 2, 6), mass=t.mass, Aam=g(t.Aam, 3, NV), Lam=g(t.Lam, 3), dLam=g(t.dLam, 3), _raw=t)
 
     def rnea(self, q, v, a):
         q, v, a = _f64(q), _f64(v), _f64(a)

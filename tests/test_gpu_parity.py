@@ -220,6 +220,48 @@ def test_active_set_stress_f64(oracle):
     assert (it_g[ok] == iters_o[ok]).mean() > 0.7 and np.abs(it_g[ok] - iters_o[ok]).max() <= 8
 
 
+def test_angular_momentum_task_f64(oracle):
+    """the legacy controller's angular-momentum task (legacy/biped.py:82-87) as three more cost
+    rows; light (legacy/op3_conf.py:15) and heavy weights, double and single support, moving states."""
+    for w_am in (1e-3, 5.0):
+        n = 48
+        wc = make(n, sim_enabled=False, w_am=w_am)
+        perturb(wc, 41, dq=0.1, dv=0.6)
+        wc.contact_active[::3, 0] = 0
+        wc.contact_active[1::5, 1] = 0
+        wc.contact_active[(wc.contact_active.sum(dim=1) == 0), 1] = 1
+        st = mirror(wc)
+        wc.tick()
+        for e in range(n):
+            out = oracle.tsid_tick(wc.params, st["q"][e], st["v"][e], st["com_ref"][e], st["posture_ref"][e], st["foot_ref"][e],
+                                   st["contact_ref"][e], st["contact_active"][e], st["cop_frames"][e])
+            st["tau"][e], st["dv"][e], st["f"][e], st["status"][e] = out["tau"], out["dv"], out["f"], out["status"]
+        assert np.array_equal(wc.status.cpu().numpy(), st["status"])
+        ok = st["status"] == 0
+        assert ok.sum() > n // 2
+        assert np.allclose(wc.dv.cpu().numpy()[ok], st["dv"][ok], rtol=1e-7, atol=1e-7)
+        assert np.allclose(wc.tau.cpu().numpy()[ok], st["tau"][ok], rtol=1e-7, atol=1e-7)
+        assert diff(wc.q[ok], st["q"][ok]) < 1e-9
+    # and the task does something: same states without it give different accelerations
+    ref = make(n, sim_enabled=False)
+    perturb(ref, 41, dq=0.1, dv=0.6)
+    ref.tick()
+    assert float((ref.dv[:, :6] - wc.dv[:, :6]).abs().max()) > 1e-2
+
+
+def test_legacy_capture_point_and_support_polygon():
+    """legacy/biped.py:224-234, batched."""
+    wc = make(4, sim_enabled=False)
+    wc.tick()
+    com = wc.obs[:, 53:56].clone()
+    dcom = torch.full((4, 3), 0.2, dtype=wc.dtype, device=wc.device)
+    cp = wc.compute_capture_point(com, dcom, w=3.0)
+    assert torch.allclose(cp[:, :2], com[:, :2] + 0.2 / 3.0) and float(cp[:, 2].abs().max()) == 0.0
+    sp = wc.compute_support_polygon()
+    assert sp.shape == (4, 2, 2) and torch.equal(sp[:, 0], wc.frames[:, 0, 9:11]) and torch.equal(sp[:, 1], wc.frames[:, 1, 9:11])
+    assert float(sp[0, 0, 0]) > 0 > float(sp[0, 1, 0])            # left sole at +x, right at -x
+
+
 def test_flight_and_single_support_ticks(oracle):
     """All four contact configurations (both, left only, right only, none) in one batch."""
     n = 64

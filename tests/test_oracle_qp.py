@@ -130,3 +130,33 @@ def test_tick_outputs(oracle, params, standing):
     assert np.allclose(obs[:27], q) and np.allclose(obs[27:53], v)
     assert np.allclose(obs[53:56], t["com"]) and np.allclose(obs[59:62], t["oMf"][0][9:])
     assert t["oMf"][1][9] < obs[56] < t["oMf"][0][9]
+
+
+def test_angular_momentum_task_enters_the_cost(oracle, params, standing, blob):
+    """SURVEY 8f-3: with w_am != 0 the cost gains w_am |A_G,ang dv + Kp L + drift|^2 (legacy/biped.py:82-87);
+    the solution keeps satisfying the KKT conditions and the momentum rate moves toward -Kp L."""
+    from tsid_control_amd.conf import RobotConfig
+    from tsid_control_amd.params import P_KP_AM, P_W_AM, pack_params
+    conf = RobotConfig()
+    conf.w_am = 1e-3                                                           # legacy/op3_conf.py:15
+    p_am = pack_params(conf, blob.effort_limit, blob.velocity_limit)
+    assert p_am[P_W_AM] == 1e-3 and list(p_am[P_KP_AM:P_KP_AM + 3]) == [10.0, 10.0, 0.0]
+    rng = np.random.default_rng(12)
+    q = standing["q"].copy()
+    q[7:] += rng.uniform(-0.05, 0.05, 20)
+    v = rng.normal(0, 0.3, NV)
+    a, b = problem(oracle, params, standing, q, v), problem(oracle, p_am, standing, q, v)
+    t = oracle.terms(q, v)
+    A = np.zeros((3, 50))
+    A[:, :26] = t["Aam"]
+    rhs = -p_am[P_KP_AM:P_KP_AM + 3] * t["Lam"] - t["dLam"]
+    assert np.abs(b["H"] - a["H"] - 1e-3 * A.T @ A).max() < 1e-15
+    assert np.abs(b["g"] - a["g"] + 1e-3 * A.T @ rhs).max() < 1e-15
+    conf.w_am = 10.0                                                           # heavy: the task is nearly met
+    p_hv = pack_params(conf, blob.effort_limit, blob.velocity_limit)
+    c = problem(oracle, p_hv, standing, q, v)
+    sa, sc = oracle.qp_solve(a["_raw"]), oracle.qp_solve(c["_raw"])
+    assert sa["status"] == 0 and sc["status"] == 0
+    kkt_check(c, sc, tol=1e-6)
+    ea, ec = np.linalg.norm(A @ sa["x"] - rhs), np.linalg.norm(A @ sc["x"] - rhs)
+    assert ec < ea                                                             # (the contact wrench cone bounds how far)

@@ -92,3 +92,36 @@ def test_se3_exp_log_roundtrip(oracle):
                       [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
                       [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
         assert np.abs(oracle.log6(R, q1[:3]) - nu).max() < 1e-9 * max(1.0, np.abs(nu).max()) + 1e-12
+
+
+def _quat_R(q):
+    x, y, z, w = q[3:7] / np.linalg.norm(q[3:7])
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                     [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                     [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+
+
+def test_centroidal_angular_momentum(oracle, standing):
+    """Angular-momentum task terms (legacy/biped.py:82-87).  A_G,ang against the mass matrix
+    (the base rows of M v are the robot's spatial momentum in the base frame, so L_G follows from CRBA
+    alone), its drift against the change of L_G along a motion with zero generalized acceleration."""
+    rng = np.random.default_rng(7)
+    for _ in range(5):
+        q, v = rand_state(rng, standing)
+        t = oracle.terms(q, v)
+        R = _quat_R(q)
+        hb = t["M"][:6] @ v                                   # momentum in the base frame, about the base origin
+        p, LO = R @ hb[:3], R @ hb[3:]
+        LG = LO - np.cross(t["com"] - q[:3], p)
+        assert np.abs(t["Aam"] @ v - LG).max() < 1e-12 and np.abs(t["Lam"] - LG).max() < 1e-12
+        assert np.abs(p - t["mass"] * t["vcom"]).max() < 1e-12  # same check on the linear part (Jcom)
+        # every column the same way: unit velocities
+        for c in (0, 4, 9, 17, 25):
+            e = np.eye(NV)[c]
+            hb = t["M"][:6] @ e
+            assert np.abs(t["Aam"][:, c] - (R @ hb[3:] - np.cross(t["com"] - q[:3], R @ hb[:3]))).max() < 1e-12
+        # drift = d/dt L_G at zero acceleration (central difference along the geodesic)
+        h = 1e-6
+        Lp = oracle.terms(oracle.integrate(q, v * h), v)["Lam"]
+        Lm = oracle.terms(oracle.integrate(q, -v * h), v)["Lam"]
+        assert np.abs((Lp - Lm) / (2 * h) - t["dLam"]).max() < 1e-6

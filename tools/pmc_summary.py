@@ -1,13 +1,47 @@
-"""Summarise rocprofv3 --pmc counter_collection.csv files: per kernel, mean counter value per dispatch."""
-import csv, sys, glob, collections
+"""Summarise rocprofv3 --pmc counter_collection.csv files: per kernel, mean counter value per dispatch.
+
+    python tools/pmc_summary.py <dir> [--last N] [--traffic-json out.json]
+--last N averages only the last N dispatches of each kernel (the timed window of bench.py; the earlier
+ones are the workload's double-support start).  --traffic-json writes the per-launch HBM bytes bench.py
+reports as roofline.traffic: k_tick = the three per-contact-configuration kernels of one tick together."""
+import collections
+import csv
+import glob
+import json
+import sys
+
 root = sys.argv[1]
+last = int(sys.argv[sys.argv.index("--last") + 1]) if "--last" in sys.argv else None
+tj = sys.argv[sys.argv.index("--traffic-json") + 1] if "--traffic-json" in sys.argv else None
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
-for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
+for f in sorted(glob.glob(root + "/**/*counter_collection.csv", recursive=True)):
+    rows = collections.defaultdict(lambda: collections.defaultdict(dict))
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"].split("(")[0].replace("void ", "")
-        if not k.startswith("k_"): continue
-        acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        if not k.startswith("k_"):
+            continue
+        # one row per (dispatch, counter[, dimension]); sum the dimensions of a dispatch
+        d = rows[k][r["Counter_Name"]]
+        did = int(r["Dispatch_Id"])
+        d[did] = d.get(did, 0.0) + float(r["Counter_Value"])
+    for k, cs in rows.items():
+        for c, d in cs.items():
+            vals = [d[i] for i in sorted(d)]
+            acc[k][c].extend(vals[-last:] if last else vals)
 for k, cs in sorted(acc.items()):
     print(k)
     for c, v in sorted(cs.items()):
         print(f"   {c:24s} mean/dispatch {sum(v)/len(v):16.1f}   (n={len(v)})")
+if tj:
+    mean = lambda k, c: sum(acc[k][c]) / len(acc[k][c]) if acc[k][c] else 0.0
+    out = {}
+    for name, kernels in (("k_tick", [k for k in acc if k.startswith("k_tick<double")]), ("k_sim", ["k_sim<double>"])):
+        fe = sum(mean(k, "FETCH_SIZE") for k in kernels)
+        wr = sum(mean(k, "WRITE_SIZE") for k in kernels)
+        out[name] = {"FETCH_SIZE_KiB": fe, "WRITE_SIZE_KiB": wr, "bytes_per_launch": 1024.0 * (fe + wr),
+                     "bytes_per_launch_fetch_x2": 1024.0 * (2 * fe + wr), "kernels": sorted(kernels),
+                     "note": "f64, 4096 walking envs, last %s dispatches of each kernel; raw FETCH_SIZE + WRITE_SIZE (KiB). "
+                             "FETCH_SIZE matches the known read byte count 1:1 on this access pattern (8 B per lane, "
+                             "env-major rows), so the gfx950 x2 correction for 16 B/lane streams is not applied in "
+                             "bytes_per_launch (bytes_per_launch_fetch_x2 applies it)." % (last or "all")}
+    json.dump(out, open(tj, "w"), indent=1)

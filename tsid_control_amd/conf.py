@@ -88,5 +88,8 @@ class RobotConfig:
     sim_enabled = True         # run the MuJoCo-subset step (main.py:192-195) after each TSID tick
     closed_loop = False        # TSID reads the sim state each tick and the sim is driven by tau
     #                            (torque actuators) instead of the reference's teleport + position servos
+    w_am = 0.0                 # angular-momentum task of legacy/biped.py:82-87 (legacy/op3_conf.py:15 uses 1e-3);
+    kp_am = 10.0               #   0 = not in the stack, as in ctrl/WalkController.py.  Gains kp_am * mask_am
+    mask_am = (1.0, 1.0, 0.0)  #   (legacy/biped.py:83), zero reference (legacy/biped.py:86-87)
     qp_max_iter = 1000         # eiquadprog-fast DEFAULT_MAX_ITER
     hessian_regularization = 1e-8  # tsid SolverHQuadProgFast default

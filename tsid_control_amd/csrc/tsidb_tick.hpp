@@ -29,12 +29,13 @@ struct KinScratch {
   T S[NV][6], fR[2][9], fp[2][3];
   union {
     T f[NJ][6];
-    struct { T arhs[4][6], acomr[3], apost[NA]; }; // a_des - drift: contact LF/RF, foot LF/RF; CoM; posture
+    struct { T arhs[4][6], acomr[3], apost[NA], aamr[3]; }; // a_des - drift: contact LF/RF, foot LF/RF; CoM; posture; AM
   };
   T Yc[NJ][10];
   union {
     struct { T R[NJ][9], p[NJ][3], V[NJ][6], A[NJ][6]; };
-    struct { T Jf[12 * LDF], Jcom[3 * LDF]; }; // frame Jacobians LOCAL (LF rows 0..5, RF 6..11), CoM Jacobian
+    struct { T Jf[12 * LDF], Jcom[3 * LDF], Jam[3 * LDF]; }; // frame Jacobians LOCAL (LF rows 0..5, RF 6..11), CoM
+                                                              // Jacobian, centroidal angular-momentum rows
   };
 };
 
@@ -60,6 +61,7 @@ struct TickLds {
   T oMf[2][12]; // frame placement: R row-major, p (world)
   T vf[2][6], af[2][6];
   T com[3], vcom[3], acomd[3];
+  T Lam[3], dLam[3]; // centroidal angular momentum and its drift (angular-momentum task)
   T qs[NQ], vs[NV];
 };
 static_assert(sizeof(ActiveSetLds<double>) <= sizeof(KinScratch<double>), "active-set state must fit the scratch region");
@@ -215,7 +217,7 @@ __device__ __forceinline__ void rbd_terms(const DevModel<T> &m, TickLds<T> &L, i
   }
   // ---- per dof: bias, F = Yc S, mass-matrix entries, CoM Jacobian column
   const T invm = T(1) / m.mass;
-  T jc[3] = {0, 0, 0};
+  T jc[3] = {0, 0, 0}, ja[3] = {0, 0, 0};
   if (lane < NV) {
     const int k = lane, jk = k < 6 ? 0 : k - 5;
     T Sk[6], Fk[6];
@@ -227,6 +229,11 @@ __device__ __forceinline__ void rbd_terms(const DevModel<T> &m, TickLds<T> &L, i
     L.h[k] = hk;
     yo_mul(K.Yc[jk], Sk, Fk);
     jc[0] = Fk[0] * invm; jc[1] = Fk[1] * invm; jc[2] = Fk[2] * invm; // CoM Jacobian column (written below)
+    // centroidal angular-momentum column: the subtree's momentum about the CoM, n_O - c x f
+    const T cx = K.Yc[0][1] * invm, cy = K.Yc[0][2] * invm, cz = K.Yc[0][3] * invm;
+    ja[0] = Fk[3] - (cy * Fk[2] - cz * Fk[1]);
+    ja[1] = Fk[4] - (cz * Fk[0] - cx * Fk[2]);
+    ja[2] = Fk[5] - (cx * Fk[1] - cy * Fk[0]);
     // M[i][k] = S_i . F_k for every dof i on the path root..k (ancestor bitmask; loads independent)
     for (unsigned mk = dofanc; mk; mk &= mk - 1) {
       const int a = __ffs(mk) - 1;
@@ -275,6 +282,13 @@ __device__ __forceinline__ void rbd_terms(const DevModel<T> &m, TickLds<T> &L, i
       L.acomd[i] = K.f[0][i] * invm - (i == 2 ? GZ : T(0));
     }
   }
+  if (lane == 3) { // rate of the centroidal angular momentum at zero acceleration (gravity has no moment about the CoM)
+    const T cx = K.Yc[0][1] * invm, cy = K.Yc[0][2] * invm, cz = K.Yc[0][3] * invm;
+    const T *f0 = K.f[0];
+    L.dLam[0] = f0[3] - (cy * f0[2] - cz * f0[1]);
+    L.dLam[1] = f0[4] - (cz * f0[0] - cx * f0[2]);
+    L.dLam[2] = f0[5] - (cx * f0[1] - cy * f0[0]);
+  }
   __syncthreads();
   // ---- frame Jacobian columns (LOCAL) and CoM velocity
   if (lane < NV) {
@@ -294,7 +308,7 @@ __device__ __forceinline__ void rbd_terms(const DevModel<T> &m, TickLds<T> &L, i
       for (int i = 0; i < 6; i++) K.Jf[(6 * f + i) * LDF + k] = col[i];
     }
 #pragma unroll
-    for (int i = 0; i < 3; i++) K.Jcom[i * LDF + k] = jc[i];
+    for (int i = 0; i < 3; i++) { K.Jcom[i * LDF + k] = jc[i]; K.Jam[i * LDF + k] = ja[i]; }
   }
   {
     T vk = lane < NV ? L.vs[lane] : T(0);
@@ -302,6 +316,13 @@ __device__ __forceinline__ void rbd_terms(const DevModel<T> &m, TickLds<T> &L, i
     for (int i = 0; i < 3; i++) {
       T tot = wave_sum(lane < NV ? jc[i] * vk : T(0));
       if (lane == 0) L.vcom[i] = tot;
+    }
+    if (m.params[P_W_AM] != 0) {
+#pragma unroll
+      for (int i = 0; i < 3; i++) {
+        T tot = wave_sum(lane < NV ? ja[i] * vk : T(0));
+        if (lane == 0) L.Lam[i] = tot;
+      }
     }
   }
   __syncthreads();
@@ -945,6 +966,9 @@ __device__ __forceinline__ void tsid_tick_env(const DevModel<T> &m, TickLds<T> &
     const int i = lane - 4;
     L.k.acomr[i] = -m.params[P_KP_COM] * (L.com[i] - com_ref[i]) - m.params[P_KD_COM] * (L.vcom[i] - com_ref[3 + i]) +
                  com_ref[6 + i] - L.acomd[i];
+  } else if (lane < 10) { // angular-momentum task, zero reference (legacy/biped.py:82-87): -Kp L - drift
+    const int i = lane - 7;
+    L.k.aamr[i] = -m.params[P_KP_AM + i] * L.Lam[i] - L.dLam[i];
   } else if (lane >= 32 && lane < 32 + NA) {
     const int r = lane - 32;
     L.k.apost[r] = -m.params[P_KP_POSTURE + r] * (L.qs[7 + r] - posture_ref[r]) - m.params[P_KD_POSTURE + r] * L.vs[6 + r];
@@ -976,7 +1000,6 @@ __device__ __forceinline__ void tsid_tick_env(const DevModel<T> &m, TickLds<T> &
 #pragma unroll
   for (int r = 0; r < 3; r++) gi -= w_com * jt[12 + r] * L.k.acomr[r];
   if (lane >= 6 && lane < NV) gi -= w_post * L.k.apost[lane - 6];
-  if (lane >= NV) gi = 0;
 #pragma unroll
   for (int j = 0; j < NV; j++) {
     T acc = 0;
@@ -986,6 +1009,22 @@ __device__ __forceinline__ void tsid_tick_env(const DevModel<T> &m, TickLds<T> &
     for (int r = 0; r < 3; r++) acc += w_com * jt[12 + r] * rdlane(jt[12 + r], j);
     a[j] = acc;
   }
+  const T w_am = m.params[P_W_AM];
+  if (w_am != 0) { // optional angular-momentum rows; wave-uniform branch
+    T ja[3];
+#pragma unroll
+    for (int r = 0; r < 3; r++) ja[r] = lane < NV ? L.k.Jam[r * LDF + (lane < NV ? lane : 0)] : T(0);
+#pragma unroll
+    for (int r = 0; r < 3; r++) gi -= w_am * ja[r] * L.k.aamr[r];
+#pragma unroll
+    for (int j = 0; j < NV; j++) {
+      T acc = 0;
+#pragma unroll
+      for (int r = 0; r < 3; r++) acc += w_am * ja[r] * rdlane(ja[r], j);
+      a[j] += acc;
+    }
+  }
+  if (lane >= NV) gi = 0;
 #pragma unroll
   for (int j = 0; j < NV; j++)
     if (lane == j) a[j] += reg + (j >= 6 ? w_post : T(0));

@@ -30,6 +30,8 @@ P_V_MAX = 91
 P_MAX_ITER = 111
 P_SIM_ENABLED = 112
 P_CLOSED_LOOP = 113
+P_W_AM = 114
+P_KP_AM = 115
 P_COUNT = 128
 
 
@@ -67,6 +69,9 @@ def pack_params(conf, effort_limit, velocity_limit):
     p[P_MAX_ITER] = getattr(conf, "qp_max_iter", 1000)
     p[P_SIM_ENABLED] = 1.0 if getattr(conf, "sim_enabled", True) else 0.0
     p[P_CLOSED_LOOP] = 1.0 if getattr(conf, "closed_loop", False) else 0.0
+    # angular-momentum task of the legacy controller (legacy/biped.py:82-87); off in ctrl/WalkController.py
+    p[P_W_AM] = getattr(conf, "w_am", 0.0)
+    p[P_KP_AM:P_KP_AM + 3] = getattr(conf, "kp_am", 10.0) * np.asarray(getattr(conf, "mask_am", (1.0, 1.0, 0.0)))
     if p[P_CLOSED_LOOP] and not p[P_SIM_ENABLED]:
         raise ValueError("closed_loop needs the sim stage (sim_enabled=True)")
     return p

@@ -273,6 +273,22 @@ class WalkController:
         cop[~both] = float("nan")
         return cop
 
+    def compute_capture_point(self, com=None, dcom=None, w=None):
+        """legacy/biped.py:224-227, batched: cp = com + dcom / w with cp_z = 0; defaults to the last tick's
+        CoM / CoM velocity (obs) and the LIPM frequency of the current CoM height."""
+        com = self.obs[:, 53:56] if com is None else com
+        if dcom is None:
+            raise ValueError("dcom (CoM velocity [N,3]) is required: the observation vector carries positions only")
+        if w is None:
+            w = torch.sqrt(9.80665 / com[:, 2:3])
+        cp = com + dcom / w
+        cp[:, 2] = 0
+        return cp
+
+    def compute_support_polygon(self):
+        """legacy/biped.py:229-234, batched: the two sole positions in the plane, [N, 2 (LF, RF), 2]."""
+        return self.frames[:, :, 9:11].clone()
+
     def integrate_dv(self, q, v, dv, dt):
         """WalkController.py:291-295 for caller-held tensors: v updated in place, new q returned.
         (step() integrates inside the kernel; this exists for callers that drive the pieces.)"""
