@@ -49,6 +49,8 @@ def parse():
     ap.add_argument("--workload", choices=["walk", "stand"], default="walk")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline budget; 0 disables it")
     ap.add_argument("--cpu-sample", type=int, default=256)
+    ap.add_argument("--sync-gather", action="store_true",
+                    help="N > 1: run the obs all-gather on the tick stream instead of a side stream")
     ap.add_argument("--no-overlap", action="store_true",
                     help="run tick and sim back to back on one stream instead of overlapping sim(t) with tick(t+1)")
     return ap.parse_args()
@@ -149,6 +151,12 @@ def main():
     q_hand = [torch.empty_like(wc.q), torch.empty_like(wc.q)]
     v_hand = [torch.empty_like(wc.v), torch.empty_like(wc.v)]
     sim_done = [None, None]
+    # N > 1: the all-gather of step t's observations runs on a third stream from a two-slot snapshot, so the
+    # collective's latency is off the tick stream's critical path (the next tick overwrites wc.obs)
+    side_gather = world > 1 and not args.sync_gather
+    s_comm = torch.cuda.Stream(device=dev) if side_gather else None
+    obs_snap = [torch.empty_like(wc.obs), torch.empty_like(wc.obs)] if side_gather else None
+    comm_done = [None, None]
 
     def one_step(i, timed_idx=None):
         par = i & 1
@@ -176,7 +184,19 @@ def main():
             if e: e[2].record(s_tick)
             wc.sim_step()
             if e: e[3].record(s_tick)
-        gather(wc.obs)
+        if side_gather:
+            if comm_done[par] is not None:
+                s_tick.wait_event(comm_done[par])
+            obs_snap[par].copy_(wc.obs)
+            snap = torch.cuda.Event()
+            snap.record(s_tick)
+            with torch.cuda.stream(s_comm):
+                s_comm.wait_event(snap)
+                gather(obs_snap[par])
+                comm_done[par] = torch.cuda.Event()
+                comm_done[par].record(s_comm)
+        else:
+            gather(wc.obs)
 
     failed_any = torch.zeros(n, dtype=torch.bool, device=dev)
     pre = args.preroll if args.workload == "walk" else 0
@@ -229,11 +249,11 @@ def main():
             "metric": "env-steps/sec (whole node)", "value": value, "unit": "env-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": ("cfg3: 4096 OP3 LIPM walking per GPU (footstep plan along the demo path, LIPM/DCM CoM "
+            "config": {"workload": (f"cfg3: {n} OP3 LIPM walking per GPU (footstep plan along the demo path, LIPM/DCM CoM "
                                     "reference + swing trajectories -> update_tasks each tick; TSID tick + sim step)"
                                     if args.workload == "walk" else
                                     "cfg2: perturbed stand/balance per GPU"),
-                       "envs_per_gpu": n, "global_envs": n * world, "preroll_steps": pre, "parallelism": f"env-sharded x{world}, obs all-gather",
+                       "envs_per_gpu": n, "global_envs": n * world, "preroll_steps": pre, "parallelism": f"env-sharded x{world}, obs all-gather" + (" on a side stream" if side_gather else ""),
                        "streams": "sim(t) overlapped with tick(t+1) on a second HIP stream" if overlap else "single stream",
                        "qp_failed_envs_last_step": n_bad, "last_step_stats": stats},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
