@@ -20,8 +20,15 @@ namespace tsidb {
 
 constexpr int LDM = 27;
 
+// floor plane n.x = d with its contact frame (mju_makeFrame: t1 from y unless |n_y| >= 0.5, t2 = n x t1)
+template <typename T>
+struct Floor {
+  T n[3], t1[3], t2[3], d;
+};
+
 template <typename T>
 struct SimLds {
+  Floor<T> fl; // per-env floor frame: read where needed instead of ten live registers per lane
   T S[NV][6];
   union { // tree-pass scratch is dead once bias forces and M exist; the Newton loop reuses the space
     struct { T V[NB][6], A[NB][6], f[NB][6], Yc[NB][10]; };
@@ -96,12 +103,6 @@ template <typename T> __device__ __forceinline__ T mulM(const SimLds<T> &L, cons
   return s;
 }
 
-// floor plane n.x = d with its contact frame (mju_makeFrame: t1 from y unless |n_y| >= 0.5, t2 = n x t1)
-template <typename T>
-struct Floor {
-  T n[3], t1[3], t2[3], d;
-};
-
 // the 4 pyramid rows of contact `c` applied to generalized vector x (LDS): J_row x
 template <typename T>
 __device__ __forceinline__ void contact_rows(const DevModel<T> &m, const SimLds<T> &L, const Floor<T> &fl, int c, const T *x,
@@ -165,10 +166,10 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
                              int *info) {
   // per-env randomisation (BASELINE config 5), NULL = nominal: mass scale, contact friction, floor plane
   const T mscale = envp ? envp[0] : T(1);
-  Floor<T> fl;
-  fl.n[0] = envp ? envp[2] : T(0); fl.n[1] = envp ? envp[3] : T(0); fl.n[2] = envp ? envp[4] : T(1);
-  fl.d = envp ? envp[5] : T(0);
-  {
+  Floor<T> &fl = L.fl;
+  if (lane == 0) {
+    fl.n[0] = envp ? envp[2] : T(0); fl.n[1] = envp ? envp[3] : T(0); fl.n[2] = envp ? envp[4] : T(1);
+    fl.d = envp ? envp[5] : T(0);
     T t[3] = {0, 0, 0};
     if (fabs(fl.n[1]) < T(0.5)) t[1] = 1; else t[2] = 1;
     const T dn = dot3(fl.n, t);
