@@ -239,7 +239,24 @@ void quat_wxyz_to_R_host(const double *q, double *R) {
   R[6] = 2 * (x * z - w * y); R[7] = 2 * (y * z + w * x); R[8] = 1 - 2 * (x * x + y * y);
 }
 
-void tree_tables(const int *parent, int n, int *depth, int *nchild, int (*child)[MAXCHILD], unsigned *anc, int *maxdepth) {
+void tree_tables(const int *parent, int n, int *depth, int *nchild, int (*child)[MAXCHILD], unsigned *anc, int *maxdepth,
+                 int *last) {
+  // subtree sums are taken as differences of a prefix scan over the lanes, which needs the numbering to be
+  // a depth-first pre-order (every subtree a contiguous index range j..last[j]); both pinocchio's joint
+  // order and MuJoCo's body order are
+  if (n > 32) throw std::string("model blob: more than 32 tree nodes");
+  for (int j = 0; j < n; j++) last[j] = j;
+  for (int j = n - 1; j > 0; j--) {
+    if (parent[j] < 0 || parent[j] >= j) throw std::string("model blob: tree nodes are not numbered parent-first");
+    if (last[j] > last[parent[j]]) last[parent[j]] = last[j];
+  }
+  for (int j = 0; j < n; j++) { // every index in (j, last[j]] must descend from j
+    for (int i = j + 1; i <= last[j]; i++) {
+      int a = i;
+      while (a > j) a = parent[a];
+      if (a != j) throw std::string("model blob: tree numbering is not a depth-first pre-order");
+    }
+  }
   *maxdepth = 0;
   for (int j = 0; j < n; j++) {
     nchild[j] = 0;
@@ -281,7 +298,7 @@ static void build_model(tsidb_ctx *h, DevModel<T> &m) {
   memset(&m, 0, sizeof m);
   // ---- TSID side
   memcpy(m.pin_parent, b.i32("pin_parent", NJ), sizeof m.pin_parent);
-  tree_tables(m.pin_parent, NJ, m.pin_depth, m.pin_nchild, m.pin_child, m.pin_anc, &m.pin_maxdepth);
+  tree_tables(m.pin_parent, NJ, m.pin_depth, m.pin_nchild, m.pin_child, m.pin_anc, &m.pin_maxdepth, m.pin_last);
   const double *pl = b.f64("pin_place", NJ * 12), *in = b.f64("pin_inertia", NJ * 10);
   double mass = 0;
   for (int j = 0; j < NJ; j++) {
@@ -371,7 +388,7 @@ static void build_model(tsidb_ctx *h, DevModel<T> &m) {
     if (m.mj_parent[j] != TOPO_PARENT[j])
       throw std::string("model blob's sim tree differs from the topology this library was compiled for "
                         "(regenerate csrc/tsidb_topology.hpp with model_compiler.py and rebuild)");
-  tree_tables(m.mj_parent, NB, m.mj_depth, m.mj_nchild, m.mj_child, m.mj_anc, &m.mj_maxdepth);
+  tree_tables(m.mj_parent, NB, m.mj_depth, m.mj_nchild, m.mj_child, m.mj_anc, &m.mj_maxdepth, m.mj_last);
   const double *mp = b.f64("mj_pos", NB * 3), *mq = b.f64("mj_quat", NB * 4), *mi = b.f64("mj_inertia", NB * 10);
   for (int j = 0; j < NB; j++) {
     double R[9];

@@ -50,6 +50,7 @@ struct DevModel {
   // ---- TSID side
   int pin_parent[NJ], pin_depth[NJ], pin_nchild[NJ], pin_child[NJ][MAXCHILD];
   unsigned pin_anc[NJ]; // bit a set <=> joint a is an ancestor of (or is) joint j
+  int pin_last[NJ];     // last index of joint j's subtree (depth-first pre-order numbering)
   int pin_maxdepth;
   T pin_place[NJ][12];   // R row-major, p
   T pin_inertia[NJ][10]; // m, c(3), Ixx Ixy Ixz Iyy Iyz Izz about c
@@ -67,6 +68,7 @@ struct DevModel {
   // ---- sim side
   int mj_parent[NB], mj_depth[NB], mj_nchild[NB], mj_child[NB][MAXCHILD];
   unsigned mj_anc[NB];
+  int mj_last[NB];
   int mj_maxdepth;
   T mj_pos[NB][3], mj_R[NB][9]; // body frame in parent (rotation from body_quat)
   T mj_inertia[NB][10];
@@ -166,6 +168,30 @@ template <typename T> __device__ __forceinline__ T wave_sum(T v) {
   v += dpp_mov<0x143, 0xc>(v); // row_bcast31 into rows 2, 3
   return lane63(v);
 }
+// Subtree sums of a tree numbered depth-first pre-order on lanes 0..31 (lane j = node j, `last` = last index
+// of j's subtree, v = 0 on unused lanes): an inclusive prefix scan over the lanes (row_shr 1, 2, 4, 8 within
+// the 16-lane rows, row_bcast15 into row 1), then S_j = (P[last_j] - P[j]) + v_j.  Replaces a depth loop of
+// LDS round trips; a leaf returns its own value exactly.
+template <typename T> __device__ __forceinline__ T bperm(T v, int src_lane) {
+  if constexpr (sizeof(T) == 4) {
+    return __builtin_bit_cast(T, __builtin_amdgcn_ds_bpermute(src_lane << 2, __builtin_bit_cast(int, v)));
+  } else {
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_ds_bpermute(src_lane << 2, (int)(b & 0xffffffffLL));
+    const int hi = __builtin_amdgcn_ds_bpermute(src_lane << 2, (int)(b >> 32));
+    return __builtin_bit_cast(T, ((long long)hi << 32) | (unsigned int)lo);
+  }
+}
+template <typename T> __device__ __forceinline__ T subtree_sum32(T v, int last) {
+  T p = v;
+  p += dpp_mov<0x111, 0xf>(p); // row_shr:1 (zero fill)
+  p += dpp_mov<0x112, 0xf>(p); // row_shr:2
+  p += dpp_mov<0x114, 0xf>(p); // row_shr:4
+  p += dpp_mov<0x118, 0xf>(p); // row_shr:8
+  p += dpp_mov<0x142, 0xa>(p); // row_bcast15 into row 1 (and 3, unused)
+  return (bperm(p, last) - p) + v;
+}
+
 template <int CTRL, int ROW_MASK, typename T> __device__ __forceinline__ T dpp_min_step(T v) {
   // lanes a disabled row would leave at 0 must not win the min: feed the lane's own value instead
   T w;

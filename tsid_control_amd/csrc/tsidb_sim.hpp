@@ -300,61 +300,49 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
     }
     __syncthreads();
   }
-  if (lane < NB) {
-    const int b = lane;
-    const T *Yb = m.mj_inertia[b];
-    T cw[3], I[9] = {mscale * Yb[4], mscale * Yb[5], mscale * Yb[6], mscale * Yb[5], mscale * Yb[7], mscale * Yb[8],
-                     mscale * Yb[6], mscale * Yb[8], mscale * Yb[9]}, Tm[9], RT[9];
-    mat3vec(Rb, Yb + 1, cw);
+  {
+    // body inertias / forces in one parallel pass, then composite inertias and subtree forces as
+    // prefix-scan differences over the lanes (bodies are numbered depth-first)
+    T fb[6] = {0, 0, 0, 0, 0, 0}, Y[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (lane < NB) {
+      const int b = lane;
+      const T *Yb = m.mj_inertia[b];
+      T cw[3], I[9] = {mscale * Yb[4], mscale * Yb[5], mscale * Yb[6], mscale * Yb[5], mscale * Yb[7], mscale * Yb[8],
+                       mscale * Yb[6], mscale * Yb[8], mscale * Yb[9]}, Tm[9], RT[9];
+      mat3vec(Rb, Yb + 1, cw);
 #pragma unroll
-    for (int i = 0; i < 3; i++) cw[i] += pb[i];
-    mat3mul(Rb, I, Tm);
+      for (int i = 0; i < 3; i++) cw[i] += pb[i];
+      mat3mul(Rb, I, Tm);
 #pragma unroll
-    for (int i = 0; i < 3; i++)
+      for (int i = 0; i < 3; i++)
 #pragma unroll
-      for (int k = 0; k < 3; k++) RT[3 * i + k] = Rb[3 * k + i];
-    mat3mul(Tm, RT, I);
-    const T mass = mscale * Yb[0], c2 = dot3(cw, cw);
-    T Y[10];
-    Y[0] = mass; Y[1] = mass * cw[0]; Y[2] = mass * cw[1]; Y[3] = mass * cw[2];
-    Y[4] = I[0] + mass * (c2 - cw[0] * cw[0]); Y[5] = I[1] - mass * cw[0] * cw[1]; Y[6] = I[2] - mass * cw[0] * cw[2];
-    Y[7] = I[4] + mass * (c2 - cw[1] * cw[1]); Y[8] = I[5] - mass * cw[1] * cw[2];
-    Y[9] = I[8] + mass * (c2 - cw[2] * cw[2]);
-    T Ag[6] = {Ab[0], Ab[1], Ab[2] - gz, Ab[3], Ab[4], Ab[5]}, Ya[6], Yv[6], vx[6];
-    yo_mul(Y, Ag, Ya);
-    yo_mul(Y, Vb, Yv);
-    cross_mf(Vb, Yv, vx);
+        for (int k = 0; k < 3; k++) RT[3 * i + k] = Rb[3 * k + i];
+      mat3mul(Tm, RT, I);
+      const T mass = mscale * Yb[0], c2 = dot3(cw, cw);
+      Y[0] = mass; Y[1] = mass * cw[0]; Y[2] = mass * cw[1]; Y[3] = mass * cw[2];
+      Y[4] = I[0] + mass * (c2 - cw[0] * cw[0]); Y[5] = I[1] - mass * cw[0] * cw[1]; Y[6] = I[2] - mass * cw[0] * cw[2];
+      Y[7] = I[4] + mass * (c2 - cw[1] * cw[1]); Y[8] = I[5] - mass * cw[1] * cw[2];
+      Y[9] = I[8] + mass * (c2 - cw[2] * cw[2]);
+      T Ag[6] = {Ab[0], Ab[1], Ab[2] - gz, Ab[3], Ab[4], Ab[5]}, Ya[6], Yv[6], vx[6];
+      yo_mul(Y, Ag, Ya);
+      yo_mul(Y, Vb, Yv);
+      cross_mf(Vb, Yv, vx);
 #pragma unroll
-    for (int i = 0; i < 6; i++) L.f[b][i] = Ya[i] + vx[i];
+      for (int i = 0; i < 6; i++) fb[i] = Ya[i] + vx[i];
+    }
+    const int mylast = lane < NB ? m.mj_last[lane] : lane;
 #pragma unroll
-    for (int i = 0; i < 10; i++) L.Yc[b][i] = Y[i];
+    for (int i = 0; i < 6; i++) fb[i] = subtree_sum32(fb[i], mylast);
+#pragma unroll
+    for (int i = 0; i < 10; i++) Y[i] = subtree_sum32(Y[i], mylast);
+    if (lane < NB) {
+#pragma unroll
+      for (int i = 0; i < 6; i++) L.f[lane][i] = fb[i];
+#pragma unroll
+      for (int i = 0; i < 10; i++) L.Yc[lane][i] = Y[i];
+    }
   }
   __syncthreads();
-  for (int dpt = m.mj_maxdepth - 1; dpt >= 0; dpt--) {
-    if (mydepth == dpt && mynchild > 0) {
-      const int b = lane;
-      T fa[6], ya[10];
-#pragma unroll
-      for (int i = 0; i < 6; i++) fa[i] = L.f[b][i];
-#pragma unroll
-      for (int i = 0; i < 10; i++) ya[i] = L.Yc[b][i];
-#pragma unroll
-      for (int ci = 0; ci < MAXCHILD; ci++) {
-        if (ci < mynchild) {
-          const int c = mychild[ci];
-#pragma unroll
-          for (int i = 0; i < 6; i++) fa[i] += L.f[c][i];
-#pragma unroll
-          for (int i = 0; i < 10; i++) ya[i] += L.Yc[c][i];
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < 6; i++) L.f[b][i] = fa[i];
-#pragma unroll
-      for (int i = 0; i < 10; i++) L.Yc[b][i] = ya[i];
-    }
-    __syncthreads();
-  }
   // ---- per dof: bias, mass-matrix column (+ armature), actuation
   T qfs = 0;
   if (lane < NV) {

@@ -88,6 +88,8 @@ template <typename T>
 __device__ __forceinline__ void rbd_terms(const DevModel<T> &m, TickLds<T> &L, int lane) {
   KinScratch<T> &K = L.k;
   const T GZ = T(9.81);
+  TSIDB_LAP_ZERO(15); TSIDB_LAP_ZERO(23); TSIDB_LAP_ZERO(29); TSIDB_LAP_ZERO(30); TSIDB_LAP_ZERO(31);
+  TSIDB_LAP_INIT();
   for (int i = lane; i < NV * LDD; i += WAVE) L.Dyn[i] = 0;
   // ---- forward pass.  Everything that does not depend on the parent (sin/cos, the joint's local
   //      rotation) is computed once up front; the depth loop carries only R, p, V, A down the tree;
@@ -135,6 +137,7 @@ __device__ __forceinline__ void rbd_terms(const DevModel<T> &m, TickLds<T> &L, i
     }
   }
   __syncthreads();
+  TSIDB_LAP(15);
   for (int dpt = 1; dpt <= m.pin_maxdepth; dpt++) {
     if (mydepth == dpt) {
       const int j = lane, p = mypar;
@@ -160,61 +163,51 @@ __device__ __forceinline__ void rbd_terms(const DevModel<T> &m, TickLds<T> &L, i
     }
     __syncthreads();
   }
-  if (lane < NJ) {
-    // body inertia about O in world axes, RNEA body force (gravity as +g base acceleration)
-    const int j = lane;
-    const T *Yb = m.pin_inertia[j];
-    T cw[3], I[9] = {Yb[4], Yb[5], Yb[6], Yb[5], Yb[7], Yb[8], Yb[6], Yb[8], Yb[9]}, Tm[9], RT[9];
-    mat3vec(Rj, Yb + 1, cw);
+  TSIDB_LAP(23);
+  {
+    // body inertia about O in world axes, RNEA body force (gravity as +g base acceleration); then the
+    // subtree sums (composite inertias, subtree forces) as prefix-scan differences over the lanes
+    T fb[6] = {0, 0, 0, 0, 0, 0}, Y[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (lane < NJ) {
+      const int j = lane;
+      const T *Yb = m.pin_inertia[j];
+      T cw[3], I[9] = {Yb[4], Yb[5], Yb[6], Yb[5], Yb[7], Yb[8], Yb[6], Yb[8], Yb[9]}, Tm[9], RT[9];
+      mat3vec(Rj, Yb + 1, cw);
 #pragma unroll
-    for (int i = 0; i < 3; i++) cw[i] += pj[i];
-    mat3mul(Rj, I, Tm);
+      for (int i = 0; i < 3; i++) cw[i] += pj[i];
+      mat3mul(Rj, I, Tm);
 #pragma unroll
-    for (int i = 0; i < 3; i++)
+      for (int i = 0; i < 3; i++)
 #pragma unroll
-      for (int k = 0; k < 3; k++) RT[3 * i + k] = Rj[3 * k + i];
-    mat3mul(Tm, RT, I);
-    T mass = Yb[0], c2 = dot3(cw, cw), Y[10];
-    Y[0] = mass; Y[1] = mass * cw[0]; Y[2] = mass * cw[1]; Y[3] = mass * cw[2];
-    Y[4] = I[0] + mass * (c2 - cw[0] * cw[0]); Y[5] = I[1] - mass * cw[0] * cw[1]; Y[6] = I[2] - mass * cw[0] * cw[2];
-    Y[7] = I[4] + mass * (c2 - cw[1] * cw[1]); Y[8] = I[5] - mass * cw[1] * cw[2];
-    Y[9] = I[8] + mass * (c2 - cw[2] * cw[2]);
-    T Ag[6] = {Aj[0], Aj[1], Aj[2] + GZ, Aj[3], Aj[4], Aj[5]}, Ya[6], Yv[6], vx[6];
-    yo_mul(Y, Ag, Ya);
-    yo_mul(Y, Vj, Yv);
-    cross_mf(Vj, Yv, vx);
+        for (int k = 0; k < 3; k++) RT[3 * i + k] = Rj[3 * k + i];
+      mat3mul(Tm, RT, I);
+      T mass = Yb[0], c2 = dot3(cw, cw);
+      Y[0] = mass; Y[1] = mass * cw[0]; Y[2] = mass * cw[1]; Y[3] = mass * cw[2];
+      Y[4] = I[0] + mass * (c2 - cw[0] * cw[0]); Y[5] = I[1] - mass * cw[0] * cw[1]; Y[6] = I[2] - mass * cw[0] * cw[2];
+      Y[7] = I[4] + mass * (c2 - cw[1] * cw[1]); Y[8] = I[5] - mass * cw[1] * cw[2];
+      Y[9] = I[8] + mass * (c2 - cw[2] * cw[2]);
+      T Ag[6] = {Aj[0], Aj[1], Aj[2] + GZ, Aj[3], Aj[4], Aj[5]}, Ya[6], Yv[6], vx[6];
+      yo_mul(Y, Ag, Ya);
+      yo_mul(Y, Vj, Yv);
+      cross_mf(Vj, Yv, vx);
 #pragma unroll
-    for (int i = 0; i < 6; i++) K.f[j][i] = Ya[i] + vx[i];
+      for (int i = 0; i < 6; i++) fb[i] = Ya[i] + vx[i];
+    }
+    TSIDB_LAP(29);
+    const int mylast = lane < NJ ? m.pin_last[lane] : lane;
 #pragma unroll
-    for (int i = 0; i < 10; i++) K.Yc[j][i] = Y[i];
+    for (int i = 0; i < 6; i++) fb[i] = subtree_sum32(fb[i], mylast);
+#pragma unroll
+    for (int i = 0; i < 10; i++) Y[i] = subtree_sum32(Y[i], mylast);
+    if (lane < NJ) {
+#pragma unroll
+      for (int i = 0; i < 6; i++) K.f[lane][i] = fb[i];
+#pragma unroll
+      for (int i = 0; i < 10; i++) K.Yc[lane][i] = Y[i];
+    }
   }
   __syncthreads();
-  // ---- backward gather by depth: subtree forces and composite inertias
-  for (int dpt = m.pin_maxdepth - 1; dpt >= 0; dpt--) {
-    if (mydepth == dpt && mynchild > 0) {
-      const int j = lane;
-      T fa[6], ya[10];
-#pragma unroll
-      for (int i = 0; i < 6; i++) fa[i] = K.f[j][i];
-#pragma unroll
-      for (int i = 0; i < 10; i++) ya[i] = K.Yc[j][i];
-#pragma unroll
-      for (int ci = 0; ci < MAXCHILD; ci++) {
-        if (ci < mynchild) {
-          const int c = mychild[ci];
-#pragma unroll
-          for (int i = 0; i < 6; i++) fa[i] += K.f[c][i];
-#pragma unroll
-          for (int i = 0; i < 10; i++) ya[i] += K.Yc[c][i];
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < 6; i++) K.f[j][i] = fa[i];
-#pragma unroll
-      for (int i = 0; i < 10; i++) K.Yc[j][i] = ya[i];
-    }
-    __syncthreads();
-  }
+  TSIDB_LAP(30);
   // ---- per dof: bias, F = Yc S, mass-matrix entries, CoM Jacobian column
   const T invm = T(1) / m.mass;
   T jc[3] = {0, 0, 0}, ja[3] = {0, 0, 0};
@@ -248,6 +241,7 @@ __device__ __forceinline__ void rbd_terms(const DevModel<T> &m, TickLds<T> &L, i
       }
     }
   }
+  TSIDB_LAP(31);
   // ---- frames (lanes 0,1): placement, velocity, classical drift acceleration (LOCAL)
   if (lane < 2) {
     const int f = lane, jf = m.frame_parent[f];
