@@ -134,6 +134,38 @@ __device__ __forceinline__ double rcp_t(double x) {
   return y;
 }
 
+// sin and cos of a joint angle together.  Joint angles are bounded (|x| < 1e3 rad is plenty), so the
+// argument reduction is two-constant Cody-Waite by pi/2 and the kernels are the classic degree-13 / 14
+// minimax polynomials on [-pi/4, pi/4] (< 1 ulp); the library sincos pays for a 1e300-proof reduction.
+__device__ __forceinline__ void sincos_t(float x, float &s, float &c) { s = sinf(x); c = cosf(x); }
+__device__ __forceinline__ void sincos_t(double x, double &s, double &c) {
+  const double k = __builtin_rint(x * 0.63661977236758134308);
+  double r = __builtin_fma(-k, 1.57079632679489655800e+00, x);
+  r = __builtin_fma(-k, 6.12323399573676603587e-17, r);
+  const double z = r * r;
+  // sin kernel: r + r z (S1 + z (S2 + ...))
+  double ps = 1.58969099521155010221e-10;
+  ps = __builtin_fma(ps, z, -2.50507602534068634195e-08);
+  ps = __builtin_fma(ps, z, 2.75573137070700676789e-06);
+  ps = __builtin_fma(ps, z, -1.98412698298579493134e-04);
+  ps = __builtin_fma(ps, z, 8.33333333332248946124e-03);
+  ps = __builtin_fma(ps, z, -1.66666666666666324348e-01);
+  const double sr = __builtin_fma(r * z, ps, r);
+  // cos kernel: 1 - z/2 + z^2 (C1 + z (C2 + ...))
+  double pc = -1.13596475577881948265e-11;
+  pc = __builtin_fma(pc, z, 2.08757232129817482790e-09);
+  pc = __builtin_fma(pc, z, -2.75573143513906633035e-07);
+  pc = __builtin_fma(pc, z, 2.48015872894767294178e-05);
+  pc = __builtin_fma(pc, z, -1.38888888888741095749e-03);
+  pc = __builtin_fma(pc, z, 4.16666666666666019037e-02);
+  const double hz = 0.5 * z, w = 1.0 - hz;
+  const double cr = w + (((1.0 - w) - hz) + z * z * pc);
+  const int q = (int)k & 3;
+  const double s0 = (q & 1) ? cr : sr, c0 = (q & 1) ? sr : cr;
+  s = (q & 2) ? -s0 : s0;
+  c = ((q + 1) & 2) ? -c0 : c0;
+}
+
 template <typename T> struct Eps;
 template <> struct Eps<double> { static constexpr double v = 2.220446049250313e-16; static constexpr double inf = 1e300; };
 template <> struct Eps<float> { static constexpr float v = 1.1920929e-07f; static constexpr float inf = 1e30f; };

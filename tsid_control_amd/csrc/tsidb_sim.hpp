@@ -265,7 +265,9 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
     for (int i = 0; i < 6; i++) { L.V[0][i] = Vb[i]; L.A[0][i] = Ab[i]; }
   } else if (lane < NB) {
     const T *Rq = m.mj_R[lane];
-    const T th = L.qpos[6 + lane], c = cos(th), s = sin(th);
+    const T th = L.qpos[6 + lane];
+    T c, s;
+    sincos_t(th, s, c);
     qd = L.qvel[5 + lane];
 #pragma unroll
     for (int i = 0; i < 3; i++) {
@@ -506,7 +508,10 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
     else if (x <= 0) imp = dmin;
     else {
       T y;
-      if (x <= mid) y = pow(x, power) / pow(mid, power - 1);
+      if (power == T(2)) { // MuJoCo's default solimp exponent: x^2 and mid^1 are exact, no pow() needed
+        if (x <= mid) y = x * x / mid;
+        else y = 1 - (1 - x) * (1 - x) / (1 - mid);
+      } else if (x <= mid) y = pow(x, power) / pow(mid, power - 1);
       else y = 1 - pow(1 - x, power) / pow(1 - mid, power - 1);
       imp = dmin + y * (dmax - dmin);
     }

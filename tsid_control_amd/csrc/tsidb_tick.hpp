@@ -127,7 +127,9 @@ __device__ __forceinline__ void rbd_terms(const DevModel<T> &m, TickLds<T> &L, i
     for (int i = 0; i < 6; i++) { K.V[0][i] = Vj[i]; K.A[0][i] = 0; }
   } else if (lane < NJ) {
     const T *PR = m.pin_place[lane];
-    const T th = L.qs[6 + lane], c = cos(th), s = sin(th);
+    const T th = L.qs[6 + lane];
+    T c, s;
+    sincos_t(th, s, c);
     qd = L.vs[5 + lane];
 #pragma unroll
     for (int i = 0; i < 3; i++) {
