@@ -239,8 +239,9 @@ void quat_wxyz_to_R_host(const double *q, double *R) {
   R[6] = 2 * (x * z - w * y); R[7] = 2 * (y * z + w * x); R[8] = 1 - 2 * (x * x + y * y);
 }
 
+template <int N>
 void tree_tables(const int *parent, int n, int *depth, int *nchild, int (*child)[MAXCHILD], unsigned *anc, int *maxdepth,
-                 int *last) {
+                 int *last, int (*up)[N]) {
   // subtree sums are taken as differences of a prefix scan over the lanes, which needs the numbering to be
   // a depth-first pre-order (every subtree a contiguous index range j..last[j]); both pinocchio's joint
   // order and MuJoCo's body order are
@@ -270,6 +271,11 @@ void tree_tables(const int *parent, int n, int *depth, int *nchild, int (*child)
       if (nchild[p] >= MAXCHILD) throw std::string("model blob: too many children per body");
       child[p][nchild[p]++] = j;
     }
+  // ancestors 1, 2, 4 levels up for the pointer-jumping forward pass (three rounds cover depth <= 7)
+  if (*maxdepth > 7) throw std::string("model blob: kinematic tree deeper than 7 levels");
+  for (int j = 0; j < n; j++) up[0][j] = parent[j];
+  for (int r = 1; r < 3; r++)
+    for (int j = 0; j < n; j++) up[r][j] = up[r - 1][j] < 0 ? -1 : up[r - 1][up[r - 1][j]];
 }
 
 } // namespace
@@ -298,7 +304,7 @@ static void build_model(tsidb_ctx *h, DevModel<T> &m) {
   memset(&m, 0, sizeof m);
   // ---- TSID side
   memcpy(m.pin_parent, b.i32("pin_parent", NJ), sizeof m.pin_parent);
-  tree_tables(m.pin_parent, NJ, m.pin_depth, m.pin_nchild, m.pin_child, m.pin_anc, &m.pin_maxdepth, m.pin_last);
+  tree_tables(m.pin_parent, NJ, m.pin_depth, m.pin_nchild, m.pin_child, m.pin_anc, &m.pin_maxdepth, m.pin_last, m.pin_up);
   const double *pl = b.f64("pin_place", NJ * 12), *in = b.f64("pin_inertia", NJ * 10);
   double mass = 0;
   for (int j = 0; j < NJ; j++) {
@@ -388,7 +394,7 @@ static void build_model(tsidb_ctx *h, DevModel<T> &m) {
     if (m.mj_parent[j] != TOPO_PARENT[j])
       throw std::string("model blob's sim tree differs from the topology this library was compiled for "
                         "(regenerate csrc/tsidb_topology.hpp with model_compiler.py and rebuild)");
-  tree_tables(m.mj_parent, NB, m.mj_depth, m.mj_nchild, m.mj_child, m.mj_anc, &m.mj_maxdepth, m.mj_last);
+  tree_tables(m.mj_parent, NB, m.mj_depth, m.mj_nchild, m.mj_child, m.mj_anc, &m.mj_maxdepth, m.mj_last, m.mj_up);
   const double *mp = b.f64("mj_pos", NB * 3), *mq = b.f64("mj_quat", NB * 4), *mi = b.f64("mj_inertia", NB * 10);
   for (int j = 0; j < NB; j++) {
     double R[9];

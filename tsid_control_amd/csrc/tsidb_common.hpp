@@ -51,6 +51,7 @@ struct DevModel {
   int pin_parent[NJ], pin_depth[NJ], pin_nchild[NJ], pin_child[NJ][MAXCHILD];
   unsigned pin_anc[NJ]; // bit a set <=> joint a is an ancestor of (or is) joint j
   int pin_last[NJ];     // last index of joint j's subtree (depth-first pre-order numbering)
+  int pin_up[3][NJ];    // ancestor 1, 2, 4 levels up (-1 beyond the root)
   int pin_maxdepth;
   T pin_place[NJ][12];   // R row-major, p
   T pin_inertia[NJ][10]; // m, c(3), Ixx Ixy Ixz Iyy Iyz Izz about c
@@ -69,6 +70,7 @@ struct DevModel {
   int mj_parent[NB], mj_depth[NB], mj_nchild[NB], mj_child[NB][MAXCHILD];
   unsigned mj_anc[NB];
   int mj_last[NB];
+  int mj_up[3][NB];
   int mj_maxdepth;
   T mj_pos[NB][3], mj_R[NB][9]; // body frame in parent (rotation from body_quat)
   T mj_inertia[NB][10];
@@ -288,6 +290,104 @@ template <typename T> __device__ __forceinline__ void cross_mf(const T *v, const
   cross3(v + 3, f, t1); cross3(v + 3, f + 3, t2); cross3(v, f, t3);
 #pragma unroll
   for (int i = 0; i < 3; i++) { o[i] = t1[i]; o[3 + i] = t2[i] + t3[i]; }
+}
+
+// Forward pass of a kinematic tree, lane j = node j (n <= 32 nodes, depth <= 7), world-aligned spatial
+// vectors about the common origin O.  In: (R, p) = the node's transform in its parent (root: in the world),
+// qd = joint rate, root only: V, A = its spatial velocity / bias acceleration.  Out: (R, p) in the world,
+// the joint's motion vector S (non-root), V, A of every node.
+//   transforms : pointer jumping - round r composes each node with its ancestor 2^r levels up (tables
+//                up0/up1/up2, -1 beyond the root), three rounds instead of one LDS round trip per level
+//   V, A       : sums over the ancestors (bitmask) of S qd and of V x (S qd), which only add in this
+//                representation
+// bufA / bufB: two n*12 scratch areas, sq / cb: n rows of >= 6 (strides given), all in LDS.
+template <typename T>
+__device__ __forceinline__ void tree_forward(int lane, int n, int up0, int up1, int up2, unsigned ancmask, T *bufA, T *bufB,
+                                             T *sq, int sq_stride, T *cb, int cb_stride, T (&R)[9], T (&p)[3], T qd,
+                                             T (&S)[6], T (&V)[6], T (&A)[6]) {
+  const bool on = lane < n;
+  if (on) {
+#pragma unroll
+    for (int i = 0; i < 9; i++) bufA[lane * 12 + i] = R[i];
+#pragma unroll
+    for (int i = 0; i < 3; i++) bufA[lane * 12 + 9 + i] = p[i];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 3; r++) {
+    const int u = r == 0 ? up0 : (r == 1 ? up1 : up2);
+    const T *src = (r & 1) ? bufB : bufA;
+    T *dst = (r & 1) ? bufA : bufB;
+    if (on && u >= 0) {
+      T Ru[9], pu[3], Rn[9], pn[3];
+#pragma unroll
+      for (int i = 0; i < 9; i++) Ru[i] = src[u * 12 + i];
+#pragma unroll
+      for (int i = 0; i < 3; i++) pu[i] = src[u * 12 + 9 + i];
+      mat3mul(Ru, R, Rn);
+      mat3vec(Ru, p, pn);
+#pragma unroll
+      for (int i = 0; i < 9; i++) R[i] = Rn[i];
+#pragma unroll
+      for (int i = 0; i < 3; i++) p[i] = pu[i] + pn[i];
+    }
+    if (r < 2) {
+      if (on) {
+#pragma unroll
+        for (int i = 0; i < 9; i++) dst[lane * 12 + i] = R[i];
+#pragma unroll
+        for (int i = 0; i < 3; i++) dst[lane * 12 + 9 + i] = p[i];
+      }
+      __syncthreads();
+    }
+  }
+  // joint motion vector (revolute about the node's z axis through p) and its rate; the root hands in V, A
+  T Sq[6];
+  if (on && lane > 0) {
+    const T a[3] = {R[2], R[5], R[8]};
+    cross3(p, a, S);
+    S[3] = a[0]; S[4] = a[1]; S[5] = a[2];
+#pragma unroll
+    for (int i = 0; i < 6; i++) Sq[i] = S[i] * qd;
+  } else {
+#pragma unroll
+    for (int i = 0; i < 6; i++) Sq[i] = V[i];
+  }
+  if (on) {
+#pragma unroll
+    for (int i = 0; i < 6; i++) sq[lane * sq_stride + i] = Sq[i];
+  }
+  __syncthreads();
+  if (on && lane > 0) {
+#pragma unroll
+    for (int i = 0; i < 6; i++) V[i] = 0;
+    for (unsigned mk = ancmask; mk; mk &= mk - 1) {
+      const int a = __ffs(mk) - 1;
+#pragma unroll
+      for (int i = 0; i < 6; i++) V[i] += sq[a * sq_stride + i];
+    }
+  }
+  T cj[6];
+  if (on && lane > 0) cross_mm(V, Sq, cj);
+  else {
+#pragma unroll
+    for (int i = 0; i < 6; i++) cj[i] = A[i];
+  }
+  if (on) {
+#pragma unroll
+    for (int i = 0; i < 6; i++) cb[lane * cb_stride + i] = cj[i];
+  }
+  __syncthreads();
+  if (on && lane > 0) {
+#pragma unroll
+    for (int i = 0; i < 6; i++) A[i] = 0;
+    for (unsigned mk = ancmask; mk; mk &= mk - 1) {
+      const int a = __ffs(mk) - 1;
+#pragma unroll
+      for (int i = 0; i < 6; i++) A[i] += cb[a * cb_stride + i];
+    }
+  }
+  __syncthreads(); // sq / cb / bufA / bufB are free again
 }
 
 // log6 of a relative placement (R row-major, p) -> [v; w]   (pinocchio::log6 semantics)

@@ -223,19 +223,18 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
 
   // ---- kinematics, velocities, bias accelerations: parent-independent work up front, the depth
   //      loop carries R, p, V, A down the tree, body inertias/forces in one parallel pass
-  T Rb[9], pb[3], Vb[6], Ab[6], Rl[9], qd = 0;
-  const int mydepth = lane < NB ? m.mj_depth[lane] : -1;
-  const int mypar = lane < NB ? m.mj_parent[lane] : 0;
-  const int mynchild = lane < NB ? m.mj_nchild[lane] : 0;
-  int mychild[MAXCHILD];
-#pragma unroll
-  for (int ci = 0; ci < MAXCHILD; ci++) mychild[ci] = lane < NB ? m.mj_child[lane][ci] : 0;
+  T Rb[9], pb[3], Vb[6], Ab[6], Sb[6], qd = 0;
+  const int up0 = lane < NB ? m.mj_up[0][lane] : -1, up1 = lane < NB ? m.mj_up[1][lane] : -1,
+            up2 = lane < NB ? m.mj_up[2][lane] : -1;
+  const unsigned bodyanc = lane < NB ? m.mj_anc[lane] : 0u;
   const unsigned dofanc = lane < NV ? m.mj_anc[lane < 6 ? 0 : lane - 5] : 0u;
-  if (lane < NB) L.anc[lane] = m.mj_anc[lane];
+  if (lane < NB) L.anc[lane] = bodyanc;
 #pragma unroll
-  for (int i = 0; i < 6; i++) { Vb[i] = 0; Ab[i] = 0; }
+  for (int i = 0; i < 6; i++) { Vb[i] = 0; Ab[i] = 0; Sb[i] = 0; }
 #pragma unroll
   for (int i = 0; i < 3; i++) pb[i] = 0;
+#pragma unroll
+  for (int i = 0; i < 9; i++) Rb[i] = 0;
   if (lane == 0) {
     quat_to_R(L.qpos[4], L.qpos[5], L.qpos[6], L.qpos[3], Rb); // wxyz storage
 #pragma unroll
@@ -257,13 +256,8 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
 #pragma unroll
       for (int i = 0; i < 6; i++) Ab[i] += dS[i] * wl[k];
     }
-#pragma unroll
-    for (int i = 0; i < 9; i++) L.R[0][i] = Rb[i];
-#pragma unroll
-    for (int i = 0; i < 3; i++) L.p[0][i] = 0;
-#pragma unroll
-    for (int i = 0; i < 6; i++) { L.V[0][i] = Vb[i]; L.A[0][i] = Ab[i]; }
   } else if (lane < NB) {
+    // the body's transform in its parent: body rotation times Rz(theta) of its hinge, body offset
     const T *Rq = m.mj_R[lane];
     const T th = L.qpos[6 + lane];
     T c, s;
@@ -271,36 +265,26 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
     qd = L.qvel[5 + lane];
 #pragma unroll
     for (int i = 0; i < 3; i++) {
-      Rl[3 * i + 0] = c * Rq[3 * i] + s * Rq[3 * i + 1];
-      Rl[3 * i + 1] = -s * Rq[3 * i] + c * Rq[3 * i + 1];
-      Rl[3 * i + 2] = Rq[3 * i + 2];
+      Rb[3 * i + 0] = c * Rq[3 * i] + s * Rq[3 * i + 1];
+      Rb[3 * i + 1] = -s * Rq[3 * i] + c * Rq[3 * i + 1];
+      Rb[3 * i + 2] = Rq[3 * i + 2];
+      pb[i] = m.mj_pos[lane][i];
     }
   }
-  __syncthreads();
-  for (int dpt = 1; dpt <= m.mj_maxdepth; dpt++) {
-    if (mydepth == dpt) {
-      const int b = lane, p = mypar;
-      mat3mul(L.R[p], Rl, Rb);
-      mat3vec(L.R[p], m.mj_pos[b], pb);
+  tree_forward<T>(lane, NB, up0, up1, up2, bodyanc, &L.R[0][0], &L.V[0][0], &L.f[0][0], 6, &L.Yc[0][0], 10, Rb, pb, qd, Sb,
+                  Vb, Ab);
+  if (lane < NB) {
+    const int b = lane;
+    if (b > 0) {
 #pragma unroll
-      for (int i = 0; i < 3; i++) pb[i] += L.p[p][i];
-      T Sj[6], a[3] = {Rb[2], Rb[5], Rb[8]}, vxs[6];
-      cross3(pb, a, Sj);
-      Sj[3] = a[0]; Sj[4] = a[1]; Sj[5] = a[2];
-      cross_mm(L.V[p], Sj, vxs);
-#pragma unroll
-      for (int i = 0; i < 6; i++) {
-        L.S[5 + b][i] = Sj[i];
-        Vb[i] = L.V[p][i] + Sj[i] * qd;
-        Ab[i] = L.A[p][i] + vxs[i] * qd;
-        L.V[b][i] = Vb[i]; L.A[b][i] = Ab[i];
-      }
-#pragma unroll
-      for (int i = 0; i < 9; i++) L.R[b][i] = Rb[i];
-#pragma unroll
-      for (int i = 0; i < 3; i++) L.p[b][i] = pb[i];
+      for (int i = 0; i < 6; i++) L.S[5 + b][i] = Sb[i];
     }
-    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 9; i++) L.R[b][i] = Rb[i];
+#pragma unroll
+    for (int i = 0; i < 3; i++) L.p[b][i] = pb[i];
+#pragma unroll
+    for (int i = 0; i < 6; i++) { L.V[b][i] = Vb[i]; L.A[b][i] = Ab[i]; }
   }
   {
     // body inertias / forces in one parallel pass, then composite inertias and subtree forces as

@@ -91,22 +91,20 @@ __device__ __forceinline__ void rbd_terms(const DevModel<T> &m, TickLds<T> &L, i
   TSIDB_LAP_ZERO(15); TSIDB_LAP_ZERO(23); TSIDB_LAP_ZERO(29); TSIDB_LAP_ZERO(30); TSIDB_LAP_ZERO(31);
   TSIDB_LAP_INIT();
   for (int i = lane; i < NV * LDD; i += WAVE) L.Dyn[i] = 0;
-  // ---- forward pass.  Everything that does not depend on the parent (sin/cos, the joint's local
-  //      rotation) is computed once up front; the depth loop carries only R, p, V, A down the tree;
+  // ---- forward pass (tree_forward: pointer jumping for the transforms, ancestor sums for V and A);
   //      body inertias and forces follow in one parallel pass.
-  T Rj[9], pj[3], Vj[6], Aj[6], Rl[9], qd = 0;
+  T Rj[9], pj[3], Vj[6], Aj[6], Sj[6], qd = 0;
   // topology into registers up front: no dependent global loads inside the tree passes
-  const int mydepth = lane < NJ ? m.pin_depth[lane] : -1;
-  const int mypar = lane < NJ ? m.pin_parent[lane] : 0;
-  const int mynchild = lane < NJ ? m.pin_nchild[lane] : 0;
-  int mychild[MAXCHILD];
-#pragma unroll
-  for (int ci = 0; ci < MAXCHILD; ci++) mychild[ci] = lane < NJ ? m.pin_child[lane][ci] : 0;
+  const int up0 = lane < NJ ? m.pin_up[0][lane] : -1, up1 = lane < NJ ? m.pin_up[1][lane] : -1,
+            up2 = lane < NJ ? m.pin_up[2][lane] : -1;
+  const unsigned jointanc = lane < NJ ? m.pin_anc[lane] : 0u;
   const unsigned dofanc = lane < NV ? m.pin_anc[lane < 6 ? 0 : lane - 5] : 0u; // ancestors of this dof's joint
 #pragma unroll
-  for (int i = 0; i < 6; i++) { Vj[i] = 0; Aj[i] = 0; }
+  for (int i = 0; i < 6; i++) { Vj[i] = 0; Aj[i] = 0; Sj[i] = 0; }
 #pragma unroll
   for (int i = 0; i < 3; i++) pj[i] = 0;
+#pragma unroll
+  for (int i = 0; i < 9; i++) Rj[i] = 0;
   if (lane == 0) {
     quat_to_R(L.qs[3], L.qs[4], L.qs[5], L.qs[6], Rj);
     mat3vec(Rj, &L.vs[0], Vj);
@@ -119,13 +117,8 @@ __device__ __forceinline__ void rbd_terms(const DevModel<T> &m, TickLds<T> &L, i
         K.S[3 + k][i] = 0; K.S[3 + k][3 + i] = Rj[3 * i + k];
       }
     }
-#pragma unroll
-    for (int i = 0; i < 9; i++) K.R[0][i] = Rj[i];
-#pragma unroll
-    for (int i = 0; i < 3; i++) K.p[0][i] = 0;
-#pragma unroll
-    for (int i = 0; i < 6; i++) { K.V[0][i] = Vj[i]; K.A[0][i] = 0; }
   } else if (lane < NJ) {
+    // the joint's transform in its parent: placement rotation times Rz(theta), placement offset
     const T *PR = m.pin_place[lane];
     const T th = L.qs[6 + lane];
     T c, s;
@@ -133,37 +126,27 @@ __device__ __forceinline__ void rbd_terms(const DevModel<T> &m, TickLds<T> &L, i
     qd = L.vs[5 + lane];
 #pragma unroll
     for (int i = 0; i < 3; i++) {
-      Rl[3 * i + 0] = c * PR[3 * i] + s * PR[3 * i + 1];
-      Rl[3 * i + 1] = -s * PR[3 * i] + c * PR[3 * i + 1];
-      Rl[3 * i + 2] = PR[3 * i + 2];
+      Rj[3 * i + 0] = c * PR[3 * i] + s * PR[3 * i + 1];
+      Rj[3 * i + 1] = -s * PR[3 * i] + c * PR[3 * i + 1];
+      Rj[3 * i + 2] = PR[3 * i + 2];
+      pj[i] = PR[9 + i];
     }
   }
-  __syncthreads();
   TSIDB_LAP(15);
-  for (int dpt = 1; dpt <= m.pin_maxdepth; dpt++) {
-    if (mydepth == dpt) {
-      const int j = lane, p = mypar;
-      mat3mul(K.R[p], Rl, Rj);
-      mat3vec(K.R[p], m.pin_place[j] + 9, pj);
+  tree_forward<T>(lane, NJ, up0, up1, up2, jointanc, &K.R[0][0], &K.V[0][0], &K.f[0][0], 6, &K.Yc[0][0], 10, Rj, pj, qd, Sj,
+                  Vj, Aj);
+  if (lane < NJ) {
+    const int j = lane;
+    if (j > 0) {
 #pragma unroll
-      for (int i = 0; i < 3; i++) pj[i] += K.p[p][i];
-      T Sj[6], a[3] = {Rj[2], Rj[5], Rj[8]}, vxs[6];
-      cross3(pj, a, Sj);
-      Sj[3] = a[0]; Sj[4] = a[1]; Sj[5] = a[2];
-      cross_mm(K.V[p], Sj, vxs);
-#pragma unroll
-      for (int i = 0; i < 6; i++) {
-        K.S[5 + j][i] = Sj[i];
-        Vj[i] = K.V[p][i] + Sj[i] * qd;
-        Aj[i] = K.A[p][i] + vxs[i] * qd;
-        K.V[j][i] = Vj[i]; K.A[j][i] = Aj[i];
-      }
-#pragma unroll
-      for (int i = 0; i < 9; i++) K.R[j][i] = Rj[i];
-#pragma unroll
-      for (int i = 0; i < 3; i++) K.p[j][i] = pj[i];
+      for (int i = 0; i < 6; i++) K.S[5 + j][i] = Sj[i];
     }
-    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 9; i++) K.R[j][i] = Rj[i];
+#pragma unroll
+    for (int i = 0; i < 3; i++) K.p[j][i] = pj[i];
+#pragma unroll
+    for (int i = 0; i < 6; i++) { K.V[j][i] = Vj[i]; K.A[j][i] = Aj[i]; }
   }
   TSIDB_LAP(23);
   {
