@@ -397,6 +397,8 @@ template <typename T> __device__ __forceinline__ void log6(const T *R, const T *
   T ct = T(0.5) * (tr - 1);
   ct = ct > 1 ? T(1) : (ct < -1 ? T(-1) : ct);
   T th = acos(ct);
+  T sth, cth;
+  sincos_t(th, sth, cth);
   T w[3] = {R[7] - R[5], R[2] - R[6], R[3] - R[1]};
   T k;
   const T small = sizeof(T) == 8 ? T(1e-8) : T(1e-4);
@@ -411,11 +413,11 @@ template <typename T> __device__ __forceinline__ void log6(const T *R, const T *
       w[i] = ax[i] * th;
     }
     k = 0;
-  } else k = T(0.5) * th / sin(th);
+  } else k = T(0.5) * th / sth;
   if (k != 0) { w[0] *= k; w[1] *= k; w[2] *= k; }
   T th2 = th * th, beta;
   if (th < T(1e-4) * (sizeof(T) == 8 ? 1 : 100)) beta = T(1.0 / 12) + th2 / 720;
-  else beta = (1 - th * sin(th) / (2 * (1 - cos(th)))) / th2;
+  else beta = (1 - th * sth / (2 * (1 - cth))) / th2;
   T wxp[3], wxwxp[3];
   cross3(w, p, wxp); cross3(w, wxp, wxwxp);
 #pragma unroll

@@ -745,8 +745,10 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
     const T th = sqrt(dot3(w, w)) * dt;
     T dq[4] = {1, 0, 0, 0};
     if (th > 0) {
-      const T s = sin(T(0.5) * th) * dt / th;
-      dq[0] = cos(T(0.5) * th); dq[1] = s * w[0]; dq[2] = s * w[1]; dq[3] = s * w[2];
+      T sh, ch;
+      sincos_t(T(0.5) * th, sh, ch);
+      const T s = sh * dt / th;
+      dq[0] = ch; dq[1] = s * w[0]; dq[2] = s * w[1]; dq[3] = s * w[2];
     }
     const T a[4] = {L.qpos[3], L.qpos[4], L.qpos[5], L.qpos[6]};
     T r[4];

@@ -1103,7 +1103,12 @@ __device__ __forceinline__ void tsid_tick_env(const DevModel<T> &m, TickLds<T> &
       const T small = sizeof(T) == 8 ? T(1e-8) : T(1e-4);
       T b, cc, sh, ch;
       if (th < small) { b = T(0.5) - th2 / 24; cc = T(1.0 / 6) - th2 / 120; sh = T(0.5) - th2 / 48; ch = 1 - th2 / 8; }
-      else { b = (1 - cos(th)) / th2; cc = (th - sin(th)) / (th2 * th); sh = sin(T(0.5) * th) / th; ch = cos(T(0.5) * th); }
+      else {
+        T s1, c1, s2, c2;
+        sincos_t(th, s1, c1);
+        sincos_t(T(0.5) * th, s2, c2);
+        b = (1 - c1) / th2; cc = (th - s1) / (th2 * th); sh = s2 / th; ch = c2;
+      }
       T wxv[3], wxwxv[3], pd[3], R0[9], rp[3];
       cross3(w, vl, wxv); cross3(w, wxv, wxwxv);
 #pragma unroll
