@@ -1,0 +1,14 @@
+#!/bin/bash
+# copy the judged summaries of a tools/final_profile.sh run from gpurun_out/<tag>_* into profiles/r01_final_*
+set -e
+TAG=${1:-r01}
+cd "$(dirname "$0")/.."
+G=gpurun_out
+cp $G/${TAG}_bench.json profiles/r01_final_bench.json
+cp $G/${TAG}_bench_no_overlap.json profiles/r01_final_bench_no_overlap.json
+cp $G/${TAG}_trace/runc/*_kernel_stats.csv profiles/r01_final_kernel_stats_overlap.csv
+cp $G/${TAG}_trace_serial/runc/*_kernel_stats.csv profiles/r01_final_kernel_stats_serial.csv
+cp $G/${TAG}_bench_under_rocprof.json profiles/r01_final_bench_under_rocprof_overlap.json
+cp $G/${TAG}_bench_under_rocprof_serial.json profiles/r01_final_bench_under_rocprof_serial.json
+python3 tools/pmc_summary.py $G/${TAG}_pmc --last 100 --traffic-json profiles/pmc_traffic.json > profiles/r01_final_pmc_walk_f64_last100.txt
+python3 tools/pmc_summary.py $G/${TAG}_pmc > profiles/r01_final_pmc_walk_f64_all.txt
