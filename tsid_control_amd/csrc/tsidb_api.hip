@@ -125,7 +125,10 @@ template <typename T>
 __global__ __launch_bounds__(256) void k_walk(int n, const T *coef, const int *side, const int *nsteps, const T *rest, const T *com,
                                               int K, T t, T Tstep, T t_start, T omega, T z0, T dz, const T *frames, T *foot_ref,
                                               T *contact_ref, uint8_t *cact, T *com_ref) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  // 16 lanes per env: every lane evaluates the (cheap) polynomials, each writes its share of the rows, so
+  // the table reads hit one line per env and the reference rows are written as contiguous runs
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int e = gid >> 4, r = gid & 15;
   if (e >= n) return;
   const size_t E = (size_t)e;
   // timeline: [0, t_start) both feet down; step k in [t_start + k T, t_start + (k+1) T); then the final stand
@@ -137,6 +140,7 @@ __global__ __launch_bounds__(256) void k_walk(int n, const T *coef, const int *s
   const int kc = kk < (ns > 0 ? ns - 1 : 0) ? kk : (ns > 0 ? ns - 1 : 0);
   const int sd = side[E * K + kc];
   const int kr = kk < ns ? kk : ns;
+  const bool act[2] = {cact[E * 2] != 0, cact[E * 2 + 1] != 0}; // read by every lane before lane 0 rewrites them
   const T *c = coef + (E * K + kc) * 16;
   const T pw[4] = {T(1), s, s * s, s * s * s}, d1[4] = {T(0), T(1), 2 * s, 3 * s * s}, d2[4] = {T(0), T(0), T(2), 6 * s};
   T pos[4], vel[4], acc[4];
@@ -152,48 +156,54 @@ __global__ __launch_bounds__(256) void k_walk(int n, const T *coef, const int *s
     const T *rs = rest + ((E * (K + 1) + kr) * 2 + f) * 4;
     const T x = swing ? pos[0] : rs[0], y = swing ? pos[1] : rs[1], z = swing ? pos[2] : rs[3], yaw = swing ? pos[3] : rs[2];
     const T cy = cos(yaw), sy = sin(yaw);
-    T smp[24] = {x, y, z, cy, sy, 0, -sy, cy, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    if (swing) {
-      smp[12] = vel[0]; smp[13] = vel[1]; smp[14] = vel[2]; smp[17] = vel[3];
-      smp[18] = acc[0]; smp[19] = acc[1]; smp[20] = acc[2]; smp[23] = acc[3];
-    }
-    const bool active = cact[E * 2 + f] != 0;
+    const bool active = act[f];
     const T *fr = frames + E * 24 + 12 * f; // R row-major, p
-    T cur[12] = {fr[9], fr[10], fr[11], fr[0], fr[3], fr[6], fr[1], fr[4], fr[7], fr[2], fr[5], fr[8]};
     T *fo = foot_ref + E * 48 + 24 * f;
-    if (!swing && !active) { // add_contact: re-reference the contact at the current placement
+    // element i of the tsid SE3 sample (p, R column-major, v6, a6) / of the current placement as an SE3 vector
+    auto smp_at = [&](int i) -> T {
+      if (i < 3) return i == 0 ? x : (i == 1 ? y : z);
+      if (i < 12) {
+        const int q = i - 3;
+        return q == 0 ? cy : q == 1 ? sy : q == 3 ? -sy : q == 4 ? cy : q == 8 ? T(1) : T(0);
+      }
+      if (!swing) return T(0);
+      const int q = i - 12, a = q < 6 ? q : q - 6;
+      const T *src = q < 6 ? vel : acc;
+      return a < 3 ? (a == 0 ? src[0] : a == 1 ? src[1] : src[2]) : (a == 5 ? src[3] : T(0));
+    };
+    auto cur_at = [&](int i) -> T { return i < 3 ? fr[9 + i] : fr[((i - 3) % 3) * 3 + (i - 3) / 3]; };
+    if (!swing && !active && r < 12) contact_ref[E * 24 + 12 * f + r] = cur_at(r); // add_contact at the current placement
 #pragma unroll
-      for (int i = 0; i < 12; i++) contact_ref[E * 24 + 12 * f + i] = cur[i];
-      cact[E * 2 + f] = 1;
+    for (int h = 0; h < 2; h++) {
+      const int i = r + 16 * h;
+      if (i < 24) fo[i] = (swing && active) ? (i < 12 ? cur_at(i) : T(0)) // remove_contact: the foot task restarts here
+                                            : smp_at(i);
     }
-    if (swing && active) { // remove_contact: the foot task restarts from the current placement
-#pragma unroll
-      for (int i = 0; i < 24; i++) fo[i] = i < 12 ? cur[i] : T(0);
-      cact[E * 2 + f] = 0;
-    } else {
-#pragma unroll
-      for (int i = 0; i < 24; i++) fo[i] = smp[i];
+    if (r == 0) {
+      if (!swing && !active) cact[E * 2 + f] = 1;
+      if (swing && active) cact[E * 2 + f] = 0;
     }
   }
   // CoM reference: LIPM segment (zmp, d, c) of the current phase in the plane, quintic descent in height
-  const int ph = k + 1 < ns + 1 ? k + 1 : ns + 1;
-  const T sc = (k >= 0 && ph > ns) ? (t - t_start) - ns * Tstep : s;
-  const T ep = exp(omega * sc), em = exp(-omega * sc);
-#pragma unroll
-  for (int a = 0; a < 2; a++) {
-    const T *sg = com + ((E * (K + 2) + ph) * 2 + a) * 3;
-    const T u = T(0.5) * sg[1] * ep + sg[2] * em;
-    com_ref[E * 9 + a] = sg[0] + u;
-    com_ref[E * 9 + 3 + a] = omega * (T(0.5) * sg[1] * ep - sg[2] * em);
-    com_ref[E * 9 + 6 + a] = omega * omega * u;
+  if (r < 9) {
+    const int ph = k + 1 < ns + 1 ? k + 1 : ns + 1;
+    const T sc = (k >= 0 && ph > ns) ? (t - t_start) - ns * Tstep : s;
+    const int a = r % 3, d = r / 3; // axis, derivative order
+    T val;
+    if (a < 2) {
+      const T ep = exp(omega * sc), em = exp(-omega * sc);
+      const T *sg = com + ((E * (K + 2) + ph) * 2 + a) * 3;
+      const T u = T(0.5) * sg[1] * ep + sg[2] * em;
+      val = d == 0 ? sg[0] + u : d == 1 ? omega * (T(0.5) * sg[1] * ep - sg[2] * em) : omega * omega * u;
+    } else {
+      const T q = t_start > 0 ? (t < t_start ? t / t_start : T(1)) : T(1);
+      const T sz = q * q * q * (10 - 15 * q + 6 * q * q);
+      const T dsz = t_start > 0 ? 30 * q * q * (1 - q) * (1 - q) / t_start : T(0);
+      const T ddsz = t_start > 0 ? 60 * q * (1 - q) * (1 - 2 * q) / (t_start * t_start) : T(0);
+      val = d == 0 ? z0 - dz * sz : d == 1 ? -dz * dsz : -dz * ddsz;
+    }
+    com_ref[E * 9 + 3 * d + a] = val;
   }
-  const T a = t_start > 0 ? (t < t_start ? t / t_start : T(1)) : T(1);
-  const T sz = a * a * a * (10 - 15 * a + 6 * a * a);
-  const T dsz = t_start > 0 ? 30 * a * a * (1 - a) * (1 - a) / t_start : T(0);
-  const T ddsz = t_start > 0 ? 60 * a * (1 - a) * (1 - 2 * a) / (t_start * t_start) : T(0);
-  com_ref[E * 9 + 2] = z0 - dz * sz;
-  com_ref[E * 9 + 5] = -dz * dsz;
-  com_ref[E * 9 + 8] = -dz * ddsz;
 }
 
 // ============================================================================ host side
@@ -640,7 +650,7 @@ int tsidb_walk_update(tsidb_handle h, const void *coef, const int32_t *side, con
   if (!coef || !side || !nsteps || !rest || !com || !frames || K <= 0) throw std::string("tsidb_walk_update: null table or K <= 0");
   if (!(step_duration > 0) || !(omega > 0) || t_start < 0) throw std::string("tsidb_walk_update: bad timing");
   hipStream_t s = (hipStream_t)stream;
-  const int grid = (h->num_envs + 255) / 256;
+  const int grid = (h->num_envs * 16 + 255) / 256;
   if (h->dtype == TSIDB_F64)
     hipLaunchKernelGGL(k_walk<double>, dim3(grid), dim3(256), 0, s, h->num_envs, (const double *)coef, side, nsteps,
                        (const double *)rest, (const double *)com, K, t, step_duration, t_start, omega, com_z0, com_drop,
