@@ -66,7 +66,8 @@ int tsidb_set_env_params(tsidb_handle h, const void *env_params);
 
 /* reset: WalkController.py:22-26,72-79 (standing state, soles onto z = 0), the references of
  * :81,122,151-152,164-165, and main.py:57-64 (mj_data.qpos = q).  env_ids (device, int32) selects
- * envs; NULL = all.  Writes state AND the reference buffers registered with tsidb_set_refs. */
+ * envs; NULL = all (a non-NULL list with n_ids = 0 resets nothing).  Writes state AND the reference buffers
+ * registered with tsidb_set_refs. */
 int tsidb_reset(tsidb_handle h, const int32_t *env_ids, int n_ids, void *q, void *v, void *qpos, void *qvel,
                 void *qacc_ws, void *stream);
 

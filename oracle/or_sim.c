@@ -170,6 +170,13 @@ int or_sim_step_full(const OrModel *m, double *qpos, double *qvel, const double 
   static __thread OrSimInfo local;
   if (!info) info = &local;
   memset(info, 0, sizeof *info);
+  { /* non-finite state / targets: the step is skipped */
+    double chk = 0;
+    for (int i = 0; i < OR_NQ; i++) chk += fabs(qpos[i]);
+    for (int i = 0; i < NV; i++) chk += fabs(qvel[i]) + fabs(qacc_ws[i]);
+    for (int i = 0; i < OR_NA; i++) chk += fabs(ctrl[i]) + (motor_tau ? fabs(motor_tau[i]) : 0.0);
+    if (!(chk <= 1e300)) return 4;
+  }
 
   /* ---------------- kinematics */
   double Rb[NB][9], pb[NB][3];

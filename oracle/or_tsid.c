@@ -469,6 +469,19 @@ int or_tsid_tick(const OrModel *m, const double *params, double *q, double *v, c
   static __thread OrTerms t;
   static __thread OrQP qp;
   static __thread OrQPSol sol;
+  { /* a non-finite state or reference never enters the solver: HQP_STATUS_ERROR, nothing touched */
+    double chk = 0;
+    for (int i = 0; i < OR_NQ; i++) chk += fabs(q[i]);
+    for (int i = 0; i < OR_NV; i++) chk += fabs(v[i]);
+    for (int i = 0; i < 9; i++) chk += fabs(com_ref[i]);
+    for (int i = 0; i < OR_NA; i++) chk += fabs(posture_ref[i]);
+    for (int i = 0; i < 48; i++) chk += fabs(foot_ref[i]);
+    for (int i = 0; i < 24; i++) chk += fabs(contact_ref[i]);
+    if (!(chk <= 1e300)) {
+      if (iters) *iters = 0;
+      return 4;
+    }
+  }
   or_rbd_terms(m, q, v, &t);
   or_tsid_assemble(m, params, &t, q, v, com_ref, posture_ref, foot_ref, contact_ref, contact_active, &qp);
   int status = or_qp_solve(&qp, (int)params[P_MAX_ITER], &sol);

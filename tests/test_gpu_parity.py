@@ -483,3 +483,83 @@ def test_api_error_behaviour():
     rc = L.tsidb_tick(h, None, None, None, None, None, None, None, None, None, None)
     assert rc != 0 and b"tsidb_set_refs" in L.tsidb_last_error(h)   # references never registered
     L.tsidb_destroy(h)
+
+
+def test_odd_batch_sizes_and_partial_reset(oracle):
+    """num_envs = 1, 3, 65 (no multiple of anything); reset(env_ids) touches only those envs; an empty id
+    list is a no-op."""
+    for n in (1, 3, 65):
+        wc = make(n)
+        perturb(wc, 100 + n)
+        st = mirror(wc)
+        for _ in range(3):
+            wc.step()
+            oracle.env_step_batch(wc.params, st, nthreads=4)
+        assert np.array_equal(wc.status.cpu().numpy(), st["status"])
+        assert diff(wc.q, st["q"]) < 1e-9 and diff(wc.qpos, st["qpos"]) < 1e-9 and diff(wc.tau, st["tau"]) < 1e-7
+        assert np.array_equal(wc.con_pairs.cpu().numpy(), st["con_geom"])
+    wc = make(6)
+    q_init, qpos_init = wc.q.clone(), wc.qpos.clone()
+    perturb(wc, 3)
+    for _ in range(4):
+        wc.step()
+    moved = wc.q.clone()
+    wc.reset(env_ids=[])
+    assert torch.equal(wc.q, moved)
+    wc.reset(env_ids=[1, 4])
+    for e in range(6):
+        if e in (1, 4):
+            assert torch.equal(wc.q[e], q_init[e]) and torch.equal(wc.qpos[e], qpos_init[e]) and float(wc.v[e].abs().max()) == 0
+        else:
+            assert torch.equal(wc.q[e], moved[e])
+
+
+def test_non_finite_inputs_are_contained(oracle):
+    """A NaN / Inf state or reference in one env: that env reports HQP_STATUS_ERROR (4) and is left as it
+    was, its neighbours are unaffected (same results as a batch without the poisoned envs); the oracle
+    restates the same guard."""
+    n = 8
+    wc, ref = make(n), make(n)
+    perturb(wc, 77); perturb(ref, 77)
+    wc.q[2, 9] = float("nan")
+    wc.com_ref[5, 1] = float("inf")
+    q_before, qpos_before = wc.q.clone(), wc.qpos.clone()
+    st = mirror(wc)
+    wc.step(); ref.step()
+    oracle.env_step_batch(wc.params, st, nthreads=2)
+    s = wc.status.cpu().numpy()
+    assert s[2] == 4 and s[5] == 4 and (np.delete(s, [2, 5]) == 0).all()
+    assert np.array_equal(s & 0xff, st["status"] & 0xff)
+    good = [0, 1, 3, 4, 6, 7]
+    assert torch.equal(wc.q[good], ref.q[good]) and torch.equal(wc.tau[good], ref.tau[good]) and torch.equal(wc.qpos[good], ref.qpos[good])
+    # poisoned envs: TSID state untouched; the sim of env 2 sees a NaN target and skips its step (info[3] bit 4)
+    assert torch.equal(wc.q[5], q_before[5]) and torch.isnan(wc.q[2, 9]) and torch.equal(wc.q[2, :9], q_before[2, :9])
+    assert int(wc.info[2, 3]) == 4 and torch.equal(wc.qpos[2], qpos_before[2])
+    assert diff(wc.qpos[good], st["qpos"][good]) < 1e-9
+
+
+def test_fallen_robot_hits_the_contact_cap(oracle):
+    """A robot lying on the floor: more hull vertices touch than the 32-contact cap; the sim keeps the
+    first 32 in body order like the oracle (bit-exact pairs) and stays finite."""
+    n = 4
+    wc = make(n)
+    st = mirror(wc)
+    # lay the sim robot on its back / side at a few heights (sim state only; no teleport)
+    quats = torch.tensor([[0.7071068, 0.7071068, 0, 0], [0.7071068, 0, 0.7071068, 0], [0.5, 0.5, 0.5, 0.5], [0.9238795, 0.3826834, 0, 0]],
+                         dtype=wc.dtype, device=wc.device)
+    wc.qpos[:, 3:7] = quats
+    wc.qpos[:, 2] = torch.tensor([0.05, 0.06, 0.05, 0.12], dtype=wc.dtype, device=wc.device)
+    wc.qpos[:, 7:] += 0.3
+    qpos, qvel, ws = wc.qpos.cpu().numpy().copy(), wc.qvel.cpu().numpy().copy(), wc.qacc_warmstart.cpu().numpy().copy()
+    ncon_max = 0
+    for _ in range(20):
+        wc.sim_step(teleport=False)
+        for e in range(n):
+            r = oracle.sim_step(qpos[e], qvel[e], np.zeros(20), ws[e])
+            got = wc.con_pairs[e].cpu().numpy()
+            want = np.full(32, -1, dtype=np.int32)
+            want[:r["ncon"]] = (r["con_geom"] << 16) | r["con_vert"]
+            assert np.array_equal(got, want)
+            ncon_max = max(ncon_max, r["ncon"])
+        assert diff(wc.qpos, qpos) < 1e-7 and diff(wc.qvel, qvel) < 1e-4
+    assert ncon_max == 32 and bool(torch.isfinite(wc.qpos).all())

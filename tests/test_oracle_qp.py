@@ -160,3 +160,19 @@ def test_angular_momentum_task_enters_the_cost(oracle, params, standing, blob):
     kkt_check(c, sc, tol=1e-6)
     ea, ec = np.linalg.norm(A @ sa["x"] - rhs), np.linalg.norm(A @ sc["x"] - rhs)
     assert ec < ea                                                             # (the contact wrench cone bounds how far)
+
+
+def test_non_finite_inputs_return_error_status(oracle, params, standing):
+    """The restated guard: a NaN / Inf state or reference gives HQP_STATUS_ERROR (4) and touches nothing."""
+    q, v = standing["q"].copy(), standing["v"].copy()
+    q[10] = np.nan
+    q0 = q.copy()
+    out = oracle.tsid_tick(params, q, v, standing["com_ref"], standing["posture_ref"], standing["foot_ref"],
+                           standing["contact_ref"], np.ones(2, np.uint8))
+    assert out["status"] == 4 and out["iters"] == 0 and np.array_equal(q0, q, equal_nan=True)
+    com = standing["com_ref"].copy()
+    com[4] = np.inf
+    q, v = standing["q"].copy(), standing["v"].copy()
+    out = oracle.tsid_tick(params, q, v, com, standing["posture_ref"], standing["foot_ref"], standing["contact_ref"],
+                           np.ones(2, np.uint8))
+    assert out["status"] == 4 and np.array_equal(q, standing["q"])

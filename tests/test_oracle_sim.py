@@ -108,3 +108,12 @@ def test_randomised_env_params(oracle):
     for _ in range(400):
         out = oracle.sim_step(qpos, qvel, np.zeros(20), ws, envp=[1, 1.0, *n, 0.0, 0, 0])
     assert out["rc"] == 0 and np.isfinite(qpos).all()
+
+
+def test_non_finite_state_skips_the_step(oracle):
+    qpos = np.zeros(NQ); qpos[2] = 0.5; qpos[3] = 1.0
+    qvel, ws = np.zeros(NV), np.zeros(NV)
+    qpos[9] = np.nan
+    before = qpos.copy()
+    r = oracle.sim_step(qpos, qvel, np.zeros(20), ws)
+    assert r["rc"] == 4 and np.array_equal(before, qpos, equal_nan=True) and r["ncon"] == 0

@@ -28,6 +28,25 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2))) void 
   if (e >= n) return;
   const size_t E = (size_t)e;
   if ((cact[E * 2] != 0) + (cact[E * 2 + 1] != 0) != NS) return;
+  {
+    // a non-finite state or reference never enters the solver: the env is flagged HQP_STATUS_ERROR (4) and
+    // left untouched (the dual active-set loop's exit tests are comparisons, which NaN makes meaningless)
+    const T *qs = qpos_sim ? qpos_sim + E * NQ : q + E * NQ, *vs = qvel_sim ? qvel_sim + E * NV : v + E * NV;
+    T chk = 0;
+    if (lane < NQ) chk += fabs(qs[lane]);
+    if (lane < NV) chk += fabs(vs[lane]);
+    if (lane < 9) chk += fabs(com_ref[E * 9 + lane]);
+    if (lane < NA) chk += fabs(posture_ref[E * NA + lane]);
+    if (lane < 48) chk += fabs(foot_ref[E * 48 + lane]);
+    if (lane < 24) chk += fabs(contact_ref[E * 24 + lane]);
+    if (__ballot(!(chk <= Eps<T>::inf))) {
+      if (lane == 0) {
+        status[e] = 4;
+        if (info) { info[E * 4] = 0; info[E * 4 + 1] = 0; }
+      }
+      return;
+    }
+  }
   tsid_tick_env<T, NS>(*mp, L, lane, q + E * NQ, v + E * NV, com_ref + E * 9, posture_ref + E * NA, foot_ref + E * 48,
                        contact_ref + E * 24, cact + E * 2, cop_frames ? cop_frames + E * 24 : nullptr, tau + E * NA,
                        dv + E * NV, f + E * 24, status + e, obs ? obs + E * NOBS : nullptr, info ? info + E * 4 : nullptr,
@@ -43,6 +62,21 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2))) void 
   const int e = blockIdx.x, lane = threadIdx.x;
   if (e >= n) return;
   const size_t E = (size_t)e;
+  {
+    // non-finite sim state / targets: skip the step, failure bit 4 in info[3]
+    T chk = 0;
+    if (lane < NQ) chk += fabs(qpos[E * NQ + lane]) + (q_tsid ? fabs(q_tsid[E * NQ + lane]) : T(0));
+    if (lane < NV) chk += fabs(qvel[E * NV + lane]) + fabs(qacc_ws[E * NV + lane]) + (v_tsid ? fabs(v_tsid[E * NV + lane]) : T(0));
+    if (lane < NA && motor_tau) chk += fabs(motor_tau[E * NA + lane]);
+    if (__ballot(!(chk <= Eps<T>::inf))) {
+      if (lane == 0) {
+        if (info) { info[E * 4 + 2] = 0; info[E * 4 + 3] = 4; }
+        if (ncon) ncon[e] = 0;
+      }
+      if (con && lane < MAXCON) con[E * MAXCON + lane] = -1;
+      return;
+    }
+  }
   sim_step_env<T>(*mp, L, lane, q_tsid ? q_tsid + E * NQ : nullptr, v_tsid ? v_tsid + E * NV : nullptr, qpos + E * NQ, qvel + E * NV, qacc_ws + E * NV,
                   env_params ? env_params + E * 8 : nullptr, motor_tau ? motor_tau + E * NA : nullptr,
                   qacc ? qacc + E * NV : nullptr, ncon ? ncon + e : nullptr, con ? con + E * MAXCON : nullptr,

@@ -157,6 +157,8 @@ class WalkController:
         if env_ids is not None:
             ids = torch.as_tensor(env_ids, dtype=torch.int32, device=self.device).contiguous()
             n_ids = ids.numel()
+            if n_ids == 0:
+                return  # nothing to reset (the C entry point reads a NULL id list as "every env")
         with torch.cuda.device(self.device):
             rc = self._L.tsidb_reset(self._h, _ptr(ids), n_ids, _ptr(self.q), _ptr(self.v), _ptr(self.qpos),
                                      _ptr(self.qvel), _ptr(self.qacc_warmstart), self._stream())
