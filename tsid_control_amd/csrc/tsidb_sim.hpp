@@ -376,15 +376,29 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
   const T Ow[3] = {L.qpos[0], L.qpos[1], L.qpos[2]};
   const T nO = dot3(fl.n, Ow) - fl.d; // signed distance of the base origin O to the floor
   int ncon = 0;
-  for (int b = 0; b < NB && ncon < MAXCON; b++) {
+  // bounding-sphere pretest for all bodies at once (lane = body, whose rotation and position are still in
+  // this lane's registers); only the bodies that can reach the floor enter the support search, in body order
+  unsigned long long cand_bodies;
+  {
+    bool near = false;
+    if (lane < NB) {
+      const T c6 = fl.n[0] * Rb[0] + fl.n[1] * Rb[3] + fl.n[2] * Rb[6];
+      const T c7 = fl.n[0] * Rb[1] + fl.n[1] * Rb[4] + fl.n[2] * Rb[7];
+      const T c8 = fl.n[0] * Rb[2] + fl.n[1] * Rb[5] + fl.n[2] * Rb[8];
+      const T pzl = dot3(fl.n, pb) + nO;
+      const T zc = c6 * m.rbound[lane][0] + c7 * m.rbound[lane][1] + c8 * m.rbound[lane][2] + pzl;
+      near = !(zc - m.rbound[lane][3] > margin);
+    }
+    cand_bodies = __ballot(near);
+  }
+  for (unsigned long long bm = cand_bodies; bm && ncon < MAXCON; bm &= bm - 1) {
+    const int b = __ffsll((long long)bm) - 1;
     const T *Rb = L.R[b];
     // floor normal in the body frame; "z" below = signed distance to the floor
     const T r6 = fl.n[0] * Rb[0] + fl.n[1] * Rb[3] + fl.n[2] * Rb[6];
     const T r7 = fl.n[0] * Rb[1] + fl.n[1] * Rb[4] + fl.n[2] * Rb[7];
     const T r8 = fl.n[0] * Rb[2] + fl.n[1] * Rb[5] + fl.n[2] * Rb[8];
     const T pz = dot3(fl.n, L.p[b]) + nO;
-    const T zc = r6 * m.rbound[b][0] + r7 * m.rbound[b][1] + r8 * m.rbound[b][2] + pz;
-    if (zc - m.rbound[b][3] > margin) continue;
     const int v0 = m.hull_adr[b], v1 = m.hull_adr[b + 1];
     // exact pruned support search: the hull's vertices are stored in k-d order, 64 per chunk, each
     // chunk with a bounding box.  A chunk can hold the lowest vertex (or one within the tie
