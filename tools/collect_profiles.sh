@@ -12,3 +12,5 @@ cp $G/${TAG}_bench_under_rocprof.json profiles/r01_final_bench_under_rocprof_ove
 cp $G/${TAG}_bench_under_rocprof_serial.json profiles/r01_final_bench_under_rocprof_serial.json
 python3 tools/pmc_summary.py $G/${TAG}_pmc --last 100 --traffic-json profiles/pmc_traffic.json > profiles/r01_final_pmc_walk_f64_last100.txt
 python3 tools/pmc_summary.py $G/${TAG}_pmc > profiles/r01_final_pmc_walk_f64_all.txt
+python3 tools/trace_window.py $G/${TAG}_trace_serial 1000 > profiles/r01_final_kernel_trace_timed_window_serial.txt
+python3 tools/trace_window.py $G/${TAG}_trace 1000 > profiles/r01_final_kernel_trace_timed_window_overlap.txt
