@@ -547,15 +547,25 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
     T cc, gg, hh;
     rows_eval(rs, T(0), cc, gg, hh);
     T cost_w = wave_sum(cc + (lane < NV ? T(0.5) * (Ma - qfs) * (xw - qas) : T(0)));
+    // keep the warm start's row residuals while the smooth solution is evaluated: whichever wins, its
+    // M a and residuals are already there (same operations on the same data as evaluating the winner again)
+    const T fjar_w = rs.fjar;
+    T cjar_w[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) cjar_w[i] = rs.cjar[i];
     stage(qas);
     jar_of(qas);
     rows_eval(rs, T(0), cc, gg, hh);
     T cost_s = wave_sum(cc);
-    if (cost_w > cost_s) { qacc = qas; }
-    else { qacc = xw; }
-    stage(qacc);
-    Ma = mulM(L, L.xv, lane);
-    jar_of(qacc);
+    if (cost_w > cost_s) {
+      qacc = qas;
+      Ma = mulM(L, L.xv, lane); // L.xv still holds qacc_smooth
+    } else {
+      qacc = xw;
+      rs.fjar = fjar_w;
+#pragma unroll
+      for (int i = 0; i < 4; i++) rs.cjar[i] = cjar_w[i];
+    }
 
     TSIDB_STAMP(20);
     const T scale = T(1) / (m.meaninertia * NV);
