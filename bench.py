@@ -49,6 +49,9 @@ def parse():
     ap.add_argument("--workload", choices=["walk", "stand"], default="walk")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline budget; 0 disables it")
     ap.add_argument("--cpu-sample", type=int, default=256)
+    ap.add_argument("--randomize", action="store_true",
+                    help="BASELINE configs[4] (not the headline): per-env mass scale U(0.8,1.2), friction U(0.4,1.0) and a "
+                         "floor plane tilted by up to 5 degrees in the sim (seed 2); use with --envs-per-gpu 65536")
     ap.add_argument("--sync-gather", action="store_true",
                     help="N > 1: run the obs all-gather on the tick stream instead of a side stream")
     ap.add_argument("--no-overlap", action="store_true",
@@ -128,6 +131,8 @@ def main():
         conf.reference_quirks = False
     wc = WalkController(conf, num_envs=n, device=dev)
     torch.manual_seed(1 + rank)
+    if args.randomize:
+        wc.randomize(seed=2 + rank)
     sched = None
     if args.workload == "walk":
         lf, rf = wc.frames[0, 0, 9:11].cpu().numpy(), wc.frames[0, 1, 9:11].cpu().numpy()
@@ -251,6 +256,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": (f"cfg3: {n} OP3 LIPM walking per GPU (footstep plan along the demo path, LIPM/DCM CoM "
                                     "reference + swing trajectories -> update_tasks each tick; TSID tick + sim step)"
+                                    + ("; cfg5 randomised mass / friction / floor tilt" if args.randomize else "")
                                     if args.workload == "walk" else
                                     "cfg2: perturbed stand/balance per GPU"),
                        "envs_per_gpu": n, "global_envs": n * world, "preroll_steps": pre, "parallelism": f"env-sharded x{world}, obs all-gather" + (" on a side stream" if side_gather else ""),
