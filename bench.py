@@ -147,15 +147,10 @@ def main():
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
 
     # The sim stage of step t only needs the TSID state tick t produced, and tick t+1 does not depend on
-    # sim t (the reference couples them one way, main.py:192-195): sim(t) runs on a second HIP stream
-    # while tick(t+1) runs on the first.  tick hands its q to the sim through a two-slot buffer; slot
-    # reuse waits on the sim that read it two steps earlier.
+    # sim t (the reference couples them one way, main.py:192-195): WalkController.step_pipelined() leaves
+    # sim(t) running on a second HIP stream while tick(t+1) runs on the first.
     overlap = not args.no_overlap
     s_tick = torch.cuda.current_stream(dev)
-    s_sim = torch.cuda.Stream(device=dev) if overlap else s_tick
-    q_hand = [torch.empty_like(wc.q), torch.empty_like(wc.q)]
-    v_hand = [torch.empty_like(wc.v), torch.empty_like(wc.v)]
-    sim_done = [None, None]
     # N > 1: the all-gather of step t's observations runs on a third stream from a two-slot snapshot, so the
     # collective's latency is off the tick stream's critical path (the next tick overwrites wc.obs)
     side_gather = world > 1 and not args.sync_gather
@@ -168,24 +163,12 @@ def main():
         if sched is not None:
             sched.apply(wc, i * conf.dt)
         e = ev[timed_idx] if timed_idx is not None else None
-        if e: e[0].record(s_tick)
-        wc.tick()
-        if e: e[1].record(s_tick)
         if overlap:
-            if sim_done[par] is not None:
-                s_tick.wait_event(sim_done[par])
-            q_hand[par].copy_(wc.q)
-            v_hand[par].copy_(wc.v)
-            ready = torch.cuda.Event()
-            ready.record(s_tick)
-            with torch.cuda.stream(s_sim):
-                s_sim.wait_event(ready)
-                if e: e[2].record(s_sim)
-                wc.sim_step(q_tsid=q_hand[par], v_tsid=v_hand[par])
-                if e: e[3].record(s_sim)
-                sim_done[par] = torch.cuda.Event()
-                sim_done[par].record(s_sim)
+            wc.step_pipelined(events=e)
         else:
+            if e: e[0].record(s_tick)
+            wc.tick()
+            if e: e[1].record(s_tick)
             if e: e[2].record(s_tick)
             wc.sim_step()
             if e: e[3].record(s_tick)

@@ -563,3 +563,19 @@ def test_fallen_robot_hits_the_contact_cap(oracle):
             ncon_max = max(ncon_max, r["ncon"])
         assert diff(wc.qpos, qpos) < 1e-7 and diff(wc.qvel, qvel) < 1e-4
     assert ncon_max == 32 and bool(torch.isfinite(wc.qpos).all())
+
+
+def test_step_pipelined_equals_step():
+    """sim(t) on a second stream overlapping tick(t+1): same results, bit for bit, as the serial step()."""
+    a, b = make(96, reference_quirks=False), make(96, reference_quirks=False)
+    perturb(a, 5); perturb(b, 5)
+    for _ in range(25):
+        a.step()
+        b.step_pipelined()
+    b.sync_sim()
+    torch.cuda.synchronize()
+    for k in ("q", "v", "tau", "dv", "f", "status", "obs", "qpos", "qvel", "qacc_warmstart", "ncon", "con_pairs", "info"):
+        assert torch.equal(getattr(a, k), getattr(b, k)), k
+    c = make(4, closed_loop=True)
+    with pytest.raises(Exception, match="step_pipelined"):
+        c.step_pipelined()

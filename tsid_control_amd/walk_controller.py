@@ -182,6 +182,54 @@ class WalkController:
         self.t += n_substeps * self.conf.dt
         return self.tau, self.q, self.v, self.status, self.obs
 
+    def step_pipelined(self, events=None):
+        """One env step with the sim stage left running on a second HIP stream, so that it overlaps with
+        what the caller enqueues next on the current stream - normally the reference update and the TSID
+        tick of the NEXT step.  The reference couples the two stages one way (the sim never feeds back into
+        TSID, main.py:119-129 vs :192-195), so sim(t) and tick(t+1) are independent; the TSID state is
+        handed to the sim through a two-slot snapshot.  tau, q, v, status, obs are valid on the current
+        stream as after step(); the sim state (qpos, qvel, qacc_warmstart, ncon, con_pairs, info[:, 2:4])
+        is valid after sync_sim().  `events` = four torch.cuda.Event recorded around the tick (current
+        stream) and around the sim (sim stream), for timing."""
+        if getattr(self.conf, "closed_loop", False) or not getattr(self.conf, "sim_enabled", True):
+            raise _lib.TsidbError("step_pipelined needs the open-loop sim stage (closed loop: the tick reads the sim state)")
+        cur = torch.cuda.current_stream(self.device)
+        if getattr(self, "_pipe", None) is None:
+            self._pipe = dict(stream=torch.cuda.Stream(device=self.device), par=0, done=[None, None],
+                              q=[torch.empty_like(self.q), torch.empty_like(self.q)],
+                              v=[torch.empty_like(self.v), torch.empty_like(self.v)])
+        P = self._pipe
+        par = P["par"]
+        P["par"] ^= 1
+        if events:
+            events[0].record(cur)
+        self.tick()
+        if events:
+            events[1].record(cur)
+        if P["done"][par] is not None:
+            cur.wait_event(P["done"][par])     # the sim that read this slot two steps ago
+        P["q"][par].copy_(self.q)
+        P["v"][par].copy_(self.v)
+        ready = torch.cuda.Event()
+        ready.record(cur)
+        with torch.cuda.stream(P["stream"]):
+            P["stream"].wait_event(ready)
+            if events:
+                events[2].record(P["stream"])
+            self.sim_step(q_tsid=P["q"][par], v_tsid=P["v"][par])
+            if events:
+                events[3].record(P["stream"])
+            P["done"][par] = torch.cuda.Event()
+            P["done"][par].record(P["stream"])
+        self.t += self.conf.dt
+        return self.tau, self.q, self.v, self.status, self.obs
+
+    def sync_sim(self):
+        """Make the current stream wait for the sim stages step_pipelined() left in flight."""
+        P = getattr(self, "_pipe", None)
+        if P is not None:
+            torch.cuda.current_stream(self.device).wait_stream(P["stream"])
+
     def tick(self):
         """TSID stage only (main.py:119-129)."""
         with torch.cuda.device(self.device):
