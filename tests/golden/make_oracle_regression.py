@@ -1,0 +1,62 @@
+"""Self-regression vectors of the CPU oracle (NOT a reference pin: the reference holds no fixtures for these
+stages and its libraries are not installed - see oracle/oracle.h).  They freeze what oracle/ computes today
+for a handful of seeded inputs, so that a later edit of the restatement that changes results is noticed.
+
+    python tests/golden/make_oracle_regression.py      # rewrites tests/golden/oracle_regression.json
+"""
+import json
+import sys
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parents[2]
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+
+
+def cases():
+    from oracle.oracle import Oracle, new_state
+    from tsid_control_amd.conf import RobotConfig
+    from tsid_control_amd.model import ModelBlob
+    from tsid_control_amd.params import pack_params
+    from conftest import se3vec
+    mb = ModelBlob(None)
+    orc = Oracle(mb.raw)
+    out = []
+    for seed, over in ((0, {}), (1, {"reference_quirks": False}), (2, {"w_am": 1e-3}), (3, {"closed_loop": True})):
+        conf = RobotConfig()
+        for k, v in over.items():
+            setattr(conf, k, v)
+        params = pack_params(conf, mb.effort_limit, mb.velocity_limit)
+        rng = np.random.default_rng(seed)
+        n = 2
+        st = new_state(n)
+        q0 = np.array(mb.q0)
+        t0 = orc.terms(q0, np.zeros(26))
+        for e in range(n):
+            st["q"][e] = q0
+            st["q"][e, 7:] += rng.uniform(-0.05, 0.05, 20)
+            st["v"][e] = rng.normal(0, 0.05, 26)
+            st["qpos"][e, :3] = q0[:3]
+            st["qpos"][e, 3:7] = [q0[6], q0[3], q0[4], q0[5]] if not conf.reference_quirks else q0[3:7]
+            st["com_ref"][e, :3] = t0["com"]
+            st["posture_ref"][e] = q0[7:]
+            for f in (0, 1):
+                st["contact_ref"][e, f] = se3vec(t0["oMf"][f])
+                st["foot_ref"][e, f, :12] = se3vec(t0["oMf"][f])
+                st["cop_frames"][e, f] = t0["oMf"][f]
+        if seed == 1:
+            st["contact_active"][1, 0] = 0
+        for _ in range(5):
+            orc.env_step_batch(params, st, nthreads=1)
+        out.append(dict(seed=seed, conf=over,
+                        **{k: np.asarray(st[k]).reshape(n, -1).tolist() for k in ("q", "v", "tau", "dv", "f", "qpos", "qvel", "obs")},
+                        status=st["status"].tolist(), ncon=st["ncon"].tolist(), con_geom=st["con_geom"].tolist()))
+    return out
+
+
+if __name__ == "__main__":
+    p = Path(__file__).with_name("oracle_regression.json")
+    p.write_text(json.dumps(cases()))
+    print("wrote", p, p.stat().st_size, "bytes")

@@ -176,3 +176,21 @@ def test_non_finite_inputs_return_error_status(oracle, params, standing):
     out = oracle.tsid_tick(params, q, v, com, standing["posture_ref"], standing["foot_ref"], standing["contact_ref"],
                            np.ones(2, np.uint8))
     assert out["status"] == 4 and np.array_equal(q, standing["q"])
+
+
+def test_oracle_self_regression():
+    """tests/golden/oracle_regression.json freezes today's oracle outputs on seeded inputs (a self-regression
+    guard for later edits of the restatement - NOT a reference pin, see the generating script)."""
+    import json
+    import sys
+    from pathlib import Path
+    g = Path(__file__).parent / "golden"
+    sys.path.insert(0, str(g))
+    import make_oracle_regression as gen
+    want = json.loads((g / "oracle_regression.json").read_text())
+    got = gen.cases()
+    assert len(want) == len(got) == 4
+    for w, c in zip(want, got):
+        assert w["status"] == c["status"] and w["ncon"] == c["ncon"] and w["con_geom"] == c["con_geom"], w["seed"]
+        for k in ("q", "v", "tau", "dv", "f", "qpos", "qvel", "obs"):
+            assert np.allclose(np.array(w[k]), np.array(c[k]), rtol=1e-9, atol=1e-10), (w["seed"], k)
