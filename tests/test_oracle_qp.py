@@ -194,3 +194,34 @@ def test_oracle_self_regression():
         assert w["status"] == c["status"] and w["ncon"] == c["ncon"] and w["con_geom"] == c["con_geom"], w["seed"]
         for k in ("q", "v", "tau", "dv", "f", "qpos", "qvel", "obs"):
             assert np.allclose(np.array(w[k]), np.array(c[k]), rtol=1e-9, atol=1e-10), (w["seed"], k)
+
+
+def test_scipy_cross_check_with_active_inequalities(oracle, params, standing):
+    """Independent solver on the captured (H, g, CE, CI): scipy's trust-constr (interior point) reaches the same optimum as the
+    restated dual active-set method on problems where inequality rows are active."""
+    from scipy.optimize import minimize
+    rng = np.random.default_rng(21)
+    checked = 0
+    for trial in range(8):
+        q = standing["q"].copy()
+        q[7:] += rng.uniform(-0.1, 0.1, 20)
+        v = rng.normal(0, 0.4, NV)
+        qp = problem(oracle, params, standing, q, v, active=(1, 1) if trial % 2 == 0 else (0, 1))
+        sol = oracle.qp_solve(qp["_raw"])
+        if sol["status"] != 0 or sol["iq"] == qp["CE"].shape[0]:
+            continue                                                            # want active inequalities
+        H, g, CE, ce0, CI, ci0 = qp["H"], qp["g"], qp["CE"], qp["ce0"], qp["CI"], qp["ci0"]
+        fun = lambda x: 0.5 * x @ H @ x + g @ x
+        jac = lambda x: H @ x + g
+        from scipy.optimize import LinearConstraint
+        cons = [LinearConstraint(CE, -ce0, -ce0), LinearConstraint(CI, -ci0, np.inf)]
+        r = minimize(fun, sol["x"] + rng.normal(0, 1e-2, len(g)), jac=jac, hess=lambda x: H, constraints=cons,
+                     method="trust-constr", options=dict(maxiter=3000, gtol=1e-10, xtol=1e-14, barrier_tol=1e-12))
+        # the interior-point iterate is feasible and can only be worse than the optimum; it must come close
+        assert np.abs(CE @ r.x + ce0).max() < 1e-6 and (CI @ r.x + ci0).min() > -1e-6
+        f_ours, f_sp = fun(sol["x"]), fun(r.x)
+        assert f_ours <= f_sp + 1e-6 * max(1.0, abs(f_sp))
+        assert abs(f_ours - f_sp) < 1e-4 * max(1.0, abs(f_sp))
+        assert np.abs(r.x[:NV] - sol["x"][:NV]).max() < 2e-2 * max(1.0, np.abs(sol["x"][:NV]).max())
+        checked += 1
+    assert checked >= 3
