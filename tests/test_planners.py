@@ -165,3 +165,24 @@ def test_walk_schedule_heading_and_phases():
     fwd = 0.5 * (end[:, 0, :2] + end[:, 1, :2]) - 0.5 * (lf + rf)
     left = lf - rf
     assert (left[0] * fwd[:, 1] - left[1] * fwd[:, 0] < 0).all() and (np.linalg.norm(fwd, axis=1) > 0.1).all()
+
+
+def test_lipm_closed_form_segment_matches_the_rollout():
+    """segment / eval_segment (what WalkSchedule tabulates and k_walk evaluates) is the continuous-time limit of
+    the reference's sampled rollout about a fixed ZMP (LIPM.py:34-49) and satisfies x'' = w^2 (x - zmp)."""
+    from tsid_control_amd.lipm import eval_segment, segment
+    lipm = LIPM(h0=0.226, dt=1e-5)
+    x0, v0, zmp = np.array([0.01, -0.02]), np.array([0.08, 0.03]), np.array([0.03, 0.0])
+    d, c = segment(lipm.w, zmp, x0, v0=v0)
+    p, v, a = eval_segment(lipm.w, zmp, d, c, 0.0)
+    assert np.allclose(p, x0) and np.allclose(v, v0) and np.allclose(a, lipm.w ** 2 * (x0 - zmp))
+    lipm.make_trajectory([0.0, 0.2], 1e-5, x0, v0, np.zeros(2), zmp)
+    for t in (0.05, 0.1, 0.19):
+        p, v, a = eval_segment(lipm.w, zmp, d, c, t)
+        # the reference's rollout uses acc = (zmp - pos) w^2, i.e. the opposite sign of the pendulum
+        # equation it names; the closed form follows the pendulum (LIPM.py:31-32's zmp identity holds for it)
+        assert np.allclose(a, lipm.w ** 2 * (p - zmp), rtol=1e-12)
+        h = 1e-6
+        fd = (eval_segment(lipm.w, zmp, d, c, t + h)[0] - 2 * p + eval_segment(lipm.w, zmp, d, c, t - h)[0]) / h ** 2
+        assert np.allclose(fd, a, rtol=1e-4, atol=1e-5)
+        assert np.allclose(p + v / lipm.w, zmp + d * np.exp(lipm.w * t))           # the DCM grows as e^{w t}

@@ -16,6 +16,7 @@ import torch
 from .conf import RobotConfig
 from .foot_trajectory import FootTrajectory
 from .footstep_planner import Footstep, FootstepPlanner, resample_path, unicycle_path
+from .lipm import GRAVITY, eval_segment, segment
 
 
 class WalkPlanner:
@@ -92,7 +93,7 @@ class WalkSchedule:
         T = conf.step_duration
         com0 = np.asarray(com0 if com0 is not None else [0.0, 0.0, 0.24], dtype=np.float64)
         self.z0, self.dz, self.t_start = float(com0[2]), float(com_drop), float(t_start)
-        self.omega = float(np.sqrt(9.80665 / (self.z0 - self.dz)))  # LIPM.py:15
+        self.omega = float(np.sqrt(GRAVITY / (self.z0 - self.dz)))  # LIPM.py:15
         w = self.omega
         coef = np.zeros((N, K, 4, 4))
         side = np.zeros((N, K), dtype=np.int64)
@@ -129,19 +130,18 @@ class WalkSchedule:
             for k in range(ns - 1, -1, -1):
                 z = steps[k + 1].position
                 xi[k] = z + (xi[k + 1] - z) * np.exp(-w * T)
-            # phase 0: constant ZMP that carries the DCM from the initial CoM to xi[0] in t_start
+            # phase 0: constant ZMP that carries the DCM from the initial CoM (at rest) to xi[0] in t_start
             x = com0[:2].copy()
             E0 = np.exp(w * t_start)
             z = (xi[0] - x * E0) / (1.0 - E0)
-            d, c = x - z, (x - z) - 0.5 * (x - z)
+            d, c = segment(w, z, x, dcm0=x)
             com[e, 0, :, 0], com[e, 0, :, 1], com[e, 0, :, 2] = z, d, c
-            x = z + 0.5 * d * E0 + c / E0
+            x = eval_segment(w, z, d, c, t_start)[0]
             for k in range(ns):
                 z = steps[k + 1].position
-                d = xi[k] - z
-                c = (x - z) - 0.5 * d
+                d, c = segment(w, z, x, dcm0=xi[k])
                 com[e, k + 1, :, 0], com[e, k + 1, :, 1], com[e, k + 1, :, 2] = z, d, c
-                x = z + 0.5 * d * np.exp(w * T) + c * np.exp(-w * T)
+                x = eval_segment(w, z, d, c, T)[0]
             com[e, ns + 1:, :, 0] = final
             com[e, ns + 1:, :, 2] = x - final
         t = lambda a, dt=dtype: torch.as_tensor(a, device=device).to(dt)
