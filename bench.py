@@ -49,6 +49,9 @@ def parse():
     ap.add_argument("--workload", choices=["walk", "stand"], default="walk")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline budget; 0 disables it")
     ap.add_argument("--cpu-sample", type=int, default=256)
+    ap.add_argument("--strong", action="store_true",
+                    help="strong scaling: --envs-per-gpu is the WHOLE job's env count, split evenly over the ranks "
+                         "(default is weak scaling: that many envs on every GPU)")
     ap.add_argument("--randomize", action="store_true",
                     help="BASELINE configs[4] (not the headline): per-env mass scale U(0.8,1.2), friction U(0.4,1.0) and a "
                          "floor plane tilted by up to 5 degrees in the sim (seed 2); use with --envs-per-gpu 65536")
@@ -123,6 +126,12 @@ def main():
     dev = torch.device("cuda", local if (world > 1 and not one_dev) else 0)
     torch.cuda.set_device(dev)
     n = args.envs_per_gpu
+    if args.strong:
+        from tsid_control_amd.sharding import shard_range
+        lo, hi = shard_range(args.envs_per_gpu, rank, world)
+        if (hi - lo) * world != args.envs_per_gpu:
+            raise SystemExit("--strong needs an env count divisible by the number of GPUs")
+        n = hi - lo
     conf = RobotConfig()
     conf.dtype = args.dtype
     if args.workload == "walk":
@@ -240,7 +249,7 @@ def main():
         out = {
             "metric": "env-steps/sec (whole node)", "value": value, "unit": "env-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": (f"cfg3: {n} OP3 LIPM walking per GPU (footstep plan along the demo path, LIPM/DCM CoM "
                                     "reference + swing trajectories -> update_tasks each tick; TSID tick + sim step)"
                                     + ("; cfg5 randomised mass / friction / floor tilt" if args.randomize else "")
