@@ -10,4 +10,16 @@ def __getattr__(name):
     if name in ("WalkController", "TrajectorySample", "map_tsid_to_mujoco"):
         from . import walk_controller
         return getattr(walk_controller, name)
+    if name in ("WalkPlanner", "WalkSchedule", "op3_walking_conf", "op3_walking_posture"):
+        from . import walk_planner
+        return getattr(walk_planner, name)
+    if name in ("Footstep", "Support", "FootstepPlanner"):
+        from . import footstep_planner
+        return getattr(footstep_planner, name)
+    if name == "FootTrajectory":
+        from .foot_trajectory import FootTrajectory
+        return FootTrajectory
+    if name in ("LIPM", "Trajectory"):
+        from . import lipm
+        return getattr(lipm, name)
     raise AttributeError(name)
