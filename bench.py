@@ -8,9 +8,16 @@
 A "step" is one pass of the hot path over one batch: for every env one TSID tick (main.py:119-129)
 and one sim step (main.py:192-195), preceded by the walking reference update that config 3 needs
 (footstep schedule -> update_tasks) and, for N > 1, followed by the RCCL all-gather of the
-observations.  Workload = BASELINE.json configs[2] "4096 OP3 LIPM walking, 1 MI355X" per GPU (weak
-scaling: configs[3] = 8 x 4096 at N = 8).  Inputs are resident in HBM before the timed region.
-Rank 0 prints ONE JSON line.
+observations, reward and done flags.
+
+Workload = BASELINE.json's metric: "env-steps/sec (whole node), 4096 OP3 walkers at 1/2/4/8 MI355X" -
+configs[2] (4096 OP3 LIPM walking) at N = 1, and for N > 1 the SAME 4096 walkers split evenly over the
+ranks (strong scaling: 2048 / 1024 / 512 per GPU).  `--weak` keeps --envs walkers on EVERY
+GPU instead (configs[3]: 8 x 4096 = 32768 at N = 8).  Inputs are resident in HBM before the timed
+region.  Rank 0 prints ONE JSON line; at N = 1 it also carries `secondary`: the unfavourable paths
+measured beside the headline (cfg2 stand at 1024 and 4096 envs, a de-phased walking batch that mixes
+50- and 38-variable QPs in one launch, and a walking batch with tightened torque bounds that drives
+envs into the dual active-set loop).
 """
 import argparse
 import json
@@ -18,6 +25,7 @@ import os
 import sys
 import time
 from pathlib import Path
+from types import SimpleNamespace
 
 import numpy as np
 import torch
@@ -27,9 +35,9 @@ sys.path.insert(0, str(ROOT))
 
 # SURVEY.md 8(d) accounting, split per kernel (words of the arithmetic type per env per launch):
 #   k_tick reads q 27, v 26, CoM ref 9, posture ref 20, foot refs 48, contact refs 24, flags 2 (156)
-#          writes q 27, v 26, tau 20, dv 26, f 24, status 1, obs 65 (189)
+#          writes q 27, v 26, tau 20, dv 26, f 24, status 1, obs 65, reward 1, done 1 (191)
 #   k_sim  reads TSID q 27, qpos 27, qvel 26, qacc_warmstart 26 (106); writes qpos 27, qvel 26, qacc_warmstart 26 (79)
-TICK_WORDS = 156 + 189
+TICK_WORDS = 156 + 191
 SIM_WORDS = 106 + 79
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured float4 copy)
 VALU_PEAK_TFLOPS = {"f64": 78.6, "f32": 157.3}
@@ -44,24 +52,37 @@ def parse():
     ap.add_argument("--preroll", type=int, default=600,
                     help="walk workload only: untimed steps of state initialisation before the warm-up, so that the "
                          "timed window starts in steady walking (the plan's first second is a double-support start)")
-    ap.add_argument("--envs-per-gpu", type=int, default=4096)
+    ap.add_argument("--envs", type=int, default=4096,
+                    help="env count of the WHOLE job, split evenly over the ranks (strong scaling, the metric's definition)")
+    ap.add_argument("--weak", action="store_true",
+                    help="weak scaling: --envs walkers on EVERY GPU (BASELINE configs[3] = 8 x 4096)")
+    ap.add_argument("--envs-per-gpu", type=int, default=None, help="same as --weak --envs N")
     ap.add_argument("--dtype", choices=["f64", "f32"], default="f64")
     ap.add_argument("--workload", choices=["walk", "stand"], default="walk")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline budget; 0 disables it")
     ap.add_argument("--cpu-sample", type=int, default=256)
-    ap.add_argument("--strong", action="store_true",
-                    help="strong scaling: --envs-per-gpu is the WHOLE job's env count, split evenly over the ranks "
-                         "(default is weak scaling: that many envs on every GPU)")
     ap.add_argument("--randomize", action="store_true",
-                    help="BASELINE configs[4] (not the headline): per-env mass scale U(0.8,1.2), friction U(0.4,1.0) and a "
-                         "floor plane tilted by up to 5 degrees in the sim (seed 2); use with --envs-per-gpu 65536")
+                    help="BASELINE configs[4] (not the headline): per-env mass scale U(0.8,1.2), friction U(0.4,1.0), a floor "
+                         "plane tilted by up to 5 degrees and 1 cm terrain steps in the sim (seed 2); use with --envs 65536")
+    ap.add_argument("--dephase", type=float, default=0.0,
+                    help="walk workload: per-env start delays U(0, DEPHASE) seconds, so that double- and single-support "
+                         "ticks mix in one launch")
+    ap.add_argument("--tau-max-scaling", type=float, default=None,
+                    help="override conf.tau_max_scaling (ctrl/conf.py:69; 5.0): small values make torque bounds active")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary measurements (N = 1 only)")
+    ap.add_argument("--secondary-steps", type=int, default=200)
     ap.add_argument("--event-every", type=int, default=int(os.environ.get("TSIDB_EVENT_EVERY", "8")),
                     help="bracket the kernels with HIP timing events on every k-th timed step only")
     ap.add_argument("--sync-gather", action="store_true",
                     help="N > 1: run the obs all-gather on the tick stream instead of a side stream")
     ap.add_argument("--no-overlap", action="store_true",
                     help="run tick and sim back to back on one stream instead of overlapping sim(t) with tick(t+1)")
-    return ap.parse_args()
+    ap.add_argument("--self-collision", type=int, default=0,
+                    help="1 = robot<->robot hull pairs collided in the sim (mj_step's behaviour), 0 = floor contacts only")
+    a = ap.parse_args()
+    if a.envs_per_gpu is not None:
+        a.weak, a.envs = True, a.envs_per_gpu
+    return a
 
 
 def host_cores():
@@ -78,10 +99,12 @@ def host_cores():
     return max(1, min(n, cap))
 
 
-def cpu_baseline(wc, seconds, sample):
-    """The oracle (a CPU port, float64) timed on this box's host cores, on a bounded sample of the
-    same workload: the first `sample` envs' state and references as they stand after warm-up."""
-    from oracle.oracle import Oracle, new_state
+def cpu_baseline(wc, sched, t_now, seconds, sample):
+    """The oracle (a CPU port, float64) timed on this box's host cores, on a bounded sample of the same
+    workload: the first `sample` envs continue from the state the GPU run left them in - for the walking
+    workload WITH the per-tick walking reference update (oracle/or_walk.c), i.e. the schedule keeps
+    stepping; for the standing workload the references are constant anyway."""
+    from oracle.oracle import Oracle, WalkTables, new_state
     n = min(sample, wc.num_envs)
     orc = Oracle(wc.model.raw)
     st = new_state(n)
@@ -89,85 +112,92 @@ def cpu_baseline(wc, seconds, sample):
         st[k][...] = getattr(wc, k)[:n].double().cpu().numpy().reshape(st[k].shape) if k != "contact_active" \
             else wc.contact_active[:n].cpu().numpy()
     st["qacc_ws"][...] = wc.qacc_warmstart[:n].double().cpu().numpy()
+    st["frames"] = np.ascontiguousarray(wc.frames[:n].double().cpu().numpy())
+    if wc.env_params is not None:
+        st["env_params"] = np.ascontiguousarray(wc.env_params[:n].double().cpu().numpy())
+    tables = WalkTables(sched, n) if sched is not None else None
     cores = host_cores()
-    orc.env_step_batch(wc.params, st, nthreads=cores)  # warm
+    dt = wc.conf.dt
+    tt = [t_now]
+
+    def one(state, nthreads, tab):
+        orc.env_step_batch(wc.params, state, nthreads=nthreads, walk=tab.at(tt[0]) if tab is not None else None)
+        tt[0] += dt
+
+    one(st, cores, tables)  # warm
     t0 = time.perf_counter()
     reps = 0
     while time.perf_counter() - t0 < seconds:
-        orc.env_step_batch(wc.params, st, nthreads=cores)
+        one(st, cores, tables)
         reps += 1
     el = time.perf_counter() - t0
     # single-thread figure on a smaller slice
     st1 = {k: np.ascontiguousarray(v[:32]) for k, v in st.items()}
+    tab1 = WalkTables(sched, min(32, n)) if sched is not None else None
     t1 = time.perf_counter()
     r1 = 0
     while time.perf_counter() - t1 < min(3.0, seconds / 4):
-        orc.env_step_batch(wc.params, st1, nthreads=1)
+        one(st1, 1, tab1)
         r1 += 1
     el1 = time.perf_counter() - t1
+    what = ("walking reference update + TSID tick + sim step per env step, the schedule keeps stepping"
+            if sched is not None else "TSID tick + sim step per env step")
     return dict(value=n * reps / el, unit="env-steps/s", cores=cores, kind="port",
-                sample=f"{n} envs (state + references captured after warm-up, references frozen) x {reps} env steps, "
+                sample=f"first {n} envs of the GPU run's final state x {reps} env steps ({what}); "
                        f"oracle/liboracle.so float64, OpenMP over envs",
-                value_1thread=32 * r1 / el1)
+                value_1thread=min(32, n) * r1 / el1)
 
 
-def main():
-    args = parse()
+def run_workload(a, dev, rank, world, n, with_gather=True):
+    """Build the workload `a` describes on `n` local envs, run preroll + warm-up untimed and a.steps timed.
+    Returns (result dict, wc, sched, time of the next tick)."""
     from tsid_control_amd import RobotConfig, WalkController
-    from tsid_control_amd.sharding import ObsGather, init_distributed
+    from tsid_control_amd.sharding import ObsGather
     from tsid_control_amd.walk_planner import WalkSchedule, op3_walking_conf, op3_walking_posture
     import torch.distributed as dist
 
-    rank, local, world = init_distributed()
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    # TSIDB_BENCH_ONE_DEVICE=1 (+ TSIDB_DIST_BACKEND=gloo) rehearses the N > 1 plumbing on a 1-GPU box
-    one_dev = os.environ.get("TSIDB_BENCH_ONE_DEVICE") == "1"
-    dev = torch.device("cuda", local if (world > 1 and not one_dev) else 0)
-    torch.cuda.set_device(dev)
-    n = args.envs_per_gpu
-    if args.strong:
-        from tsid_control_amd.sharding import shard_range
-        lo, hi = shard_range(args.envs_per_gpu, rank, world)
-        if (hi - lo) * world != args.envs_per_gpu:
-            raise SystemExit("--strong needs an env count divisible by the number of GPUs")
-        n = hi - lo
     conf = RobotConfig()
-    conf.dtype = args.dtype
-    if args.workload == "walk":
+    conf.dtype = a.dtype
+    conf.self_collision = bool(a.self_collision)
+    if a.workload == "walk":
         # OP3-sized steps and walking task weights (walk_planner.op3_walking_conf explains why conf.py's
         # own values cannot walk); the sim follows the true base orientation (quirk F6a would tip it over
         # as soon as the path turns)
         op3_walking_conf(conf)
         conf.reference_quirks = False
+    if a.tau_max_scaling is not None:
+        conf.tau_max_scaling = a.tau_max_scaling
     wc = WalkController(conf, num_envs=n, device=dev)
     torch.manual_seed(1 + rank)
-    if args.randomize:
+    if a.randomize:
         wc.randomize(seed=2 + rank)
     sched = None
-    if args.workload == "walk":
+    if a.workload == "walk":
         lf, rf = wc.frames[0, 0, 9:11].cpu().numpy(), wc.frames[0, 1, 9:11].cpu().numpy()
         wc.posture_ref += torch.as_tensor(op3_walking_posture(), device=dev).to(wc.dtype)
         sched = WalkSchedule.from_demo_paths(n, conf, dev, wc.dtype, seed=1 + rank, q0_feet=(lf, rf),
                                              com0=wc.com_ref[0, :3].double().cpu().numpy())
+        if a.dephase > 0:
+            g = torch.Generator().manual_seed(7 + rank)
+            sched.set_phase_offsets(torch.rand(n, generator=g, dtype=torch.float64) * a.dephase)
     else:  # config 2: perturbed standing
         wc.q[:, 7:] += (torch.rand(n, 20, dtype=wc.dtype, device=dev) - 0.5) * 0.1
         wc.v[:] = torch.randn(n, 26, dtype=wc.dtype, device=dev) * 0.05
-    gather = ObsGather(n, 65, world, wc.dtype, dev)
-    total = args.warmup + args.steps
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] if k % args.event_every == 0 else None
-          for k in range(args.steps)]
+    # the gathered row per env: obs[65] + reward + done (SURVEY.md 8e "obs (+reward, done)")
+    gather = ObsGather(n, wc.gather_width, world, wc.dtype, dev) if with_gather else None
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] if k % a.event_every == 0 else None
+          for k in range(a.steps)]
 
     # The sim stage of step t only needs the TSID state tick t produced, and tick t+1 does not depend on
     # sim t (the reference couples them one way, main.py:192-195): WalkController.step_pipelined() leaves
     # sim(t) running on a second HIP stream while tick(t+1) runs on the first.
-    overlap = not args.no_overlap
+    overlap = not a.no_overlap
     s_tick = torch.cuda.current_stream(dev)
-    # N > 1: the all-gather of step t's observations runs on a third stream from a two-slot snapshot, so the
-    # collective's latency is off the tick stream's critical path (the next tick overwrites wc.obs)
-    side_gather = world > 1 and not args.sync_gather
+    # N > 1: the all-gather of step t's rows runs on a third stream from a two-slot snapshot, so the
+    # collective's latency is off the tick stream's critical path (the next tick overwrites the rows)
+    side_gather = with_gather and world > 1 and not a.sync_gather
     s_comm = torch.cuda.Stream(device=dev) if side_gather else None
-    obs_snap = [torch.empty_like(wc.obs), torch.empty_like(wc.obs)] if side_gather else None
+    snap_buf = [torch.empty(n, wc.gather_width, dtype=wc.dtype, device=dev) for _ in range(2)] if side_gather else None
     comm_done = [None, None]
 
     def one_step(i, timed_idx=None):
@@ -184,88 +214,181 @@ def main():
             if e: e[2].record(s_tick)
             wc.sim_step()
             if e: e[3].record(s_tick)
+        if gather is None:
+            return
         if side_gather:
             if comm_done[par] is not None:
                 s_tick.wait_event(comm_done[par])
-            obs_snap[par].copy_(wc.obs)
+            wc.gather_rows(out=snap_buf[par])
             snap = torch.cuda.Event()
             snap.record(s_tick)
             with torch.cuda.stream(s_comm):
                 s_comm.wait_event(snap)
-                gather(obs_snap[par])
+                gather(snap_buf[par])
                 comm_done[par] = torch.cuda.Event()
                 comm_done[par].record(s_comm)
         else:
-            gather(wc.obs)
+            gather(wc.gather_rows())
 
     failed_any = torch.zeros(n, dtype=torch.bool, device=dev)
-    pre = args.preroll if args.workload == "walk" else 0
-    for i in range(pre + args.warmup):
+    n_samples = 0
+    stride = max(1, min(64, a.steps))
+    pre = a.preroll if a.workload == "walk" else 0
+    for i in range(pre + a.warmup):
         one_step(i)
-    if world > 1:
+    if world > 1 and with_gather:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for k in range(args.steps):
-        one_step(pre + args.warmup + k, k)
-        if k % 64 == 63:
-            failed_any |= wc.status != 0   # sampled every 64th step: one tiny kernel, not per step
+    for k in range(a.steps):
+        one_step(pre + a.warmup + k, k)
+        if k % stride == stride - 1 or k == a.steps - 1:
+            failed_any |= wc.status != 0   # sampled: one tiny kernel, not per step
+            n_samples += 1
     torch.cuda.synchronize()
-    if world > 1:
+    if world > 1 and with_gather:
         dist.barrier()
     el = time.perf_counter() - t0
-    elt = torch.tensor([el], dtype=torch.float64, device=dev)
-    if world > 1:
+    if world > 1 and with_gather:
+        elt = torch.tensor([el], dtype=torch.float64, device=dev)
         dist.all_reduce(elt, op=dist.ReduceOp.MAX)
-    el = float(elt.item())
+        el = float(elt.item())
+    wc.sync_sim()
+    torch.cuda.synchronize()
 
     evs = [e for e in ev if e is not None]
     tick_ms = sum(e[0].elapsed_time(e[1]) for e in evs) / len(evs)
     sim_ms = sum(e[2].elapsed_time(e[3]) for e in evs) / len(evs)
-    wsz = 8 if args.dtype == "f64" else 4
-    dom, dom_ms, dom_words = ("k_tick", tick_ms, TICK_WORDS) if tick_ms >= sim_ms else ("k_sim", sim_ms, SIM_WORDS)
-    alg_bytes = n * dom_words * wsz
-    achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
-    n_bad = int((wc.status != 0).sum().item())
     qp_it = wc.info[:, 0].float()
     stats = {"qp_iters_mean": float(qp_it.mean()), "qp_iters_max": int(qp_it.max()),
              "frac_envs_in_active_set_loop": float((qp_it > 1).float().mean()),
              "active_rows_mean": float(wc.info[:, 1].float().mean()), "ncon_mean": float(wc.ncon.float().mean()),
              "newton_iters_mean": float(wc.info[:, 2].float().mean()),
              "single_support_frac": float((wc.contact_active.sum(dim=1) == 1).float().mean()),
-             "envs_with_a_failed_qp_in_sampled_steps": int(failed_any.sum().item()),
+             "double_support_frac": float((wc.contact_active.sum(dim=1) == 2).float().mean()),
+             "envs_with_a_failed_qp_in_sampled_steps": int(failed_any.sum().item()), "failed_qp_samples": n_samples,
+             "qp_failed_envs_last_step": int((wc.status != 0).sum().item()),
+             "sim_flagged_envs_last_step": int((wc.info[:, 3] != 0).sum().item()),
+             "done_envs_last_step": int(wc.done.sum().item()),
              "com_tracking_err_max_m": float((wc.obs[:, 53:56] - wc.com_ref[:, :3]).abs().max()),
              "base_height_min_m": float(wc.q[:, 2].min())}
+    res = dict(el=el, tick_ms=tick_ms, sim_ms=sim_ms, stats=stats, pre=pre, overlap=overlap, side_gather=side_gather)
+    return res, wc, sched, (pre + a.warmup + a.steps) * conf.dt
 
-    traffic = traffic_x2 = None
+
+def workload_name(a, n):
+    if a.workload == "walk":
+        s = (f"cfg3: {n} OP3 LIPM walking per GPU (footstep plan along the demo path, LIPM/DCM CoM reference + swing "
+             "trajectories -> update_tasks each tick; TSID tick + sim step")
+        s += ", robot<->robot hull pairs collided)" if a.self_collision else ", floor contacts only)"
+        if a.randomize:
+            s += "; cfg5 randomised mass / friction / floor tilt + 1 cm terrain steps"
+        if a.dephase > 0:
+            s += f"; per-env start delays U(0, {a.dephase} s)"
+        if a.tau_max_scaling is not None:
+            s += f"; tau_max_scaling {a.tau_max_scaling}"
+        return s
+    return f"cfg2: {n} perturbed stand/balance per GPU"
+
+
+def secondary_runs(a, dev):
+    """The unfavourable paths beside the headline, each a short run of its own."""
+    out = {}
+    base = dict(dtype=a.dtype, randomize=False, dephase=0.0, tau_max_scaling=None, steps=a.secondary_steps, warmup=20,
+                preroll=600, event_every=4, no_overlap=a.no_overlap, sync_gather=False, self_collision=a.self_collision)
+    cases = [
+        ("cfg2_stand_1024", dict(workload="stand", steps=max(a.secondary_steps, 400), warmup=200), 1024),
+        ("cfg2_stand_4096", dict(workload="stand", steps=max(a.secondary_steps, 400), warmup=200), 4096),
+        # window centred on t = 1.5 s with start delays U(0, 1 s): about half the envs are still in the
+        # double-support start (50-variable QP), the rest in single support (38 variables)
+        ("cfg3_walk_4096_dephased", dict(workload="walk", dephase=1.0, preroll=700 - a.secondary_steps // 2), 4096),
+        ("cfg3_walk_4096_tight_torque_bounds", dict(workload="walk", tau_max_scaling=0.12), 4096),
+    ]
+    for name, over, n in cases:
+        b = SimpleNamespace(**{**base, **over})
+        res, wc, _, _ = run_workload(b, dev, 0, 1, n, with_gather=False)
+        out[name] = {"workload": workload_name(b, n), "value": n * b.steps / res["el"], "unit": "env-steps/s",
+                     "steps": b.steps, "ms_per_step": 1e3 * res["el"] / b.steps, "k_tick_ms": res["tick_ms"],
+                     "k_sim_ms": res["sim_ms"], "last_step_stats": res["stats"]}
+        del wc
+        torch.cuda.empty_cache()
+    return out
+
+
+def main():
+    args = parse()
+    from tsid_control_amd.sharding import init_distributed, shard_range
+    import torch.distributed as dist
+
+    rank, local, world = init_distributed()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    # TSIDB_BENCH_ONE_DEVICE=1 (+ TSIDB_DIST_BACKEND=gloo) rehearses the N > 1 plumbing on a 1-GPU box
+    one_dev = os.environ.get("TSIDB_BENCH_ONE_DEVICE") == "1"
+    dev = torch.device("cuda", local if (world > 1 and not one_dev) else 0)
+    torch.cuda.set_device(dev)
+    if args.weak:
+        n = args.envs
+    else:
+        lo, hi = shard_range(args.envs, rank, world)
+        if (hi - lo) * world != args.envs:
+            raise SystemExit("the env count must be divisible by the number of GPUs")
+        n = hi - lo
+    res, wc, sched, t_next = run_workload(args, dev, rank, world, n)
+    el, tick_ms, sim_ms = res["el"], res["tick_ms"], res["sim_ms"]
+
+    wsz = 8 if args.dtype == "f64" else 4
+    dom, dom_ms, dom_words = ("k_tick", tick_ms, TICK_WORDS) if tick_ms >= sim_ms else ("k_sim", sim_ms, SIM_WORDS)
+    if args.randomize and dom == "k_sim":
+        dom_words += 8 + 20  # env_params row + terrain table row
+    alg_bytes = n * dom_words * wsz
+    achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
+
+    # HBM traffic is NOT measured by this run: it comes from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
+    # passes (tools/pmc_profile.sh) and is reported only for the configuration those passes were taken on
+    traffic = traffic_src = pmc = None
     tf = ROOT / "profiles" / "pmc_traffic.json"
-    if tf.exists() and args.dtype == "f64" and n == 4096:
-        # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/pmc_profile.sh), committed under profiles/
-        rec = json.loads(tf.read_text()).get(dom, {})
-        traffic, traffic_x2 = rec.get("bytes_per_launch"), rec.get("bytes_per_launch_fetch_x2")
+    if tf.exists():
+        rec_all = json.loads(tf.read_text())
+        cond = rec_all.get("measured_on", {})
+        same = (args.dtype == cond.get("dtype", "f64") and n == cond.get("envs", 4096) and args.workload == cond.get("workload", "walk")
+                and not args.randomize and args.dephase == 0 and args.tau_max_scaling is None
+                and int(args.self_collision) == int(cond.get("self_collision", 0)))
+        if same:
+            rec = rec_all.get(dom, {})
+            traffic = rec.get("bytes_per_launch")
+            traffic_src = f"profiles/pmc_traffic.json ({rec_all.get('source', 'rocprofv3 --pmc passes')}; not measured by this run)"
+            pmc = rec_all.get("valu", {}).get(dom)
 
     if rank == 0:
         value = world * n * args.steps / el
         out = {
             "metric": "env-steps/sec (whole node)", "value": value, "unit": "env-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps,
-            "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": (f"cfg3: {n} OP3 LIPM walking per GPU (footstep plan along the demo path, LIPM/DCM CoM "
-                                    "reference + swing trajectories -> update_tasks each tick; TSID tick + sim step)"
-                                    + ("; cfg5 randomised mass / friction / floor tilt" if args.randomize else "")
-                                    if args.workload == "walk" else
-                                    "cfg2: perturbed stand/balance per GPU"),
-                       "envs_per_gpu": n, "global_envs": n * world, "preroll_steps": pre, "parallelism": f"env-sharded x{world}, obs all-gather" + (" on a side stream" if side_gather else ""),
-                       "streams": "sim(t) overlapped with tick(t+1) on a second HIP stream" if overlap else "single stream",
-                       "qp_failed_envs_last_step": n_bad, "last_step_stats": stats},
+            "higher_is_better": True, "scaling": "weak" if args.weak else "strong", "vs_baseline": None, "dtype": args.dtype,
+            "data": "synthetic",
+            "config": {"workload": workload_name(args, n),
+                       "envs_per_gpu": n, "global_envs": n * world, "preroll_steps": res["pre"],
+                       "parallelism": f"env-sharded x{world}, all-gather of obs + reward + done"
+                                      + (" on a side stream" if res["side_gather"] else ""),
+                       "streams": "sim(t) overlapped with tick(t+1) on a second HIP stream" if res["overlap"] else "single stream",
+                       "qp_failed_envs_last_step": res["stats"]["qp_failed_envs_last_step"], "last_step_stats": res["stats"]},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_fetch_x2": traffic_x2,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": dom_ms,
                          "k_tick_ms": tick_ms, "k_sim_ms": sim_ms,
+                         # what actually binds these kernels (DESIGN.md section 5): VALU issue + dependency latency of
+                         # one wavefront per env; the HBM fraction above is reported because the north star asks for it
+                         "binding_resource": "valu-issue + dependency latency (one wavefront per env)",
+                         "valu_issue_from_profiles": pmc,
                          "valu_frac_nominal": (n * NOMINAL_FLOP_PER_ENV_STEP / ((tick_ms + sim_ms) * 1e-3)) / (VALU_PEAK_TFLOPS[args.dtype] * 1e12)},
         }
         if world == 1 and args.cpu_seconds > 0:
-            out["cpu_baseline"] = cpu_baseline(wc, args.cpu_seconds, args.cpu_sample)
+            out["cpu_baseline"] = cpu_baseline(wc, sched, t_next, args.cpu_seconds, args.cpu_sample)
+        if world == 1 and not args.no_secondary:
+            del wc
+            torch.cuda.empty_cache()
+            out["secondary"] = secondary_runs(args, dev)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

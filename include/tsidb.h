@@ -23,7 +23,7 @@ extern "C" {
 typedef struct tsidb_ctx *tsidb_handle;
 
 enum { TSIDB_F64 = 0, TSIDB_F32 = 1 };
-enum { TSIDB_NQ = 27, TSIDB_NV = 26, TSIDB_NA = 20, TSIDB_NOBS = 65, TSIDB_MAXCON = 32 };
+enum { TSIDB_NQ = 27, TSIDB_NV = 26, TSIDB_NA = 20, TSIDB_NOBS = 65, TSIDB_NROW = 67, TSIDB_MAXCON = 32 };
 
 /* parameter vector (float64, host): RobotConfig values the reference hands to its task
  * constructors (ctrl/conf.py:21-72 via ctrl/WalkController.py:55-184) */
@@ -35,6 +35,11 @@ enum {
   TSIDB_P_KD_POSTURE = TSIDB_P_KP_POSTURE + 20, TSIDB_P_TAU_MAX = TSIDB_P_KD_POSTURE + 20,
   TSIDB_P_V_MAX = TSIDB_P_TAU_MAX + 20, TSIDB_P_MAX_ITER = TSIDB_P_V_MAX + 20, TSIDB_P_SIM_ENABLED, TSIDB_P_CLOSED_LOOP,
   TSIDB_P_W_AM /* angular-momentum task weight (legacy/biped.py:82-87), 0 = not in the stack */, TSIDB_P_KP_AM /*3*/,
+  /* reward / done outputs (SURVEY.md 8d write list; no reference counterpart): reward = exp(-|com - com_ref|^2 / sigma^2)
+   * - c_tau |tau|^2, done = failed QP, base height < DONE_HEIGHT or base z-axis . world z < DONE_TILT */
+  TSIDB_P_REW_SIGMA = TSIDB_P_KP_AM + 3, TSIDB_P_REW_CTAU, TSIDB_P_DONE_HEIGHT, TSIDB_P_DONE_TILT,
+  TSIDB_P_SELF_COLLISION /* sim: collide the robot<->robot hull pairs as mj_step does (main.py:195); 0 = floor only */,
+  TSIDB_P_W_COP /* CoP force task weight (legacy/biped.py:79-80), 0 = not in the stack */,
   TSIDB_P_COUNT = 128
 };
 
@@ -73,10 +78,12 @@ int tsidb_reset(tsidb_handle h, const int32_t *env_ids, int n_ids, void *q, void
 
 /* one TSID tick for every env: main.py:119-129 (+ readouts :132-142).
  * q [N,27], v [N,26] updated in place; tau [N,20], dv [N,26], f [N,24] (LF 12, RF 12), status [N],
- * obs [N,65] = q v com cop LF RF (may be NULL), frames [N,2,12] sole placements R row-major + p
- * (may be NULL), info [N,4] int32 = qp iterations, active-set size, -, - (may be NULL). */
+ * obs [N,obs_ld] = q v com cop LF RF (65 values; may be NULL; obs_ld >= 65 is the row stride in elements -
+ * with obs_ld >= TSIDB_NROW columns 65, 66 receive reward and done, so that one contiguous [N,67] buffer is
+ * what the all-gather sends), frames [N,2,12] sole placements R row-major + p (may be NULL), info [N,4]
+ * int32 = qp iterations, active-set size, -, - (may be NULL). */
 int tsidb_tick(tsidb_handle h, void *q, void *v, void *tau, void *dv, void *f, int32_t *status, void *obs,
-               void *frames, int32_t *info, void *stream);
+               int obs_ld, void *frames, int32_t *info, void *stream);
 
 /* one sim step for every env: main.py:192-195.  q_tsid [N,27] (NULL = no teleport, ctrl = 0); v_tsid
  * [N,26] (may be NULL) is used only with params[QUIRKS] = 0: the base velocity is then set together with
@@ -93,7 +100,7 @@ int tsidb_sim(tsidb_handle h, const void *q_tsid, const void *v_tsid, void *qpos
  * linear velocity -> body frame, sim joint order -> TSID order), and the sim stage applies tau as motor
  * torques and keeps its own base pose instead of the teleport + position servos. */
 int tsidb_step(tsidb_handle h, void *q, void *v, void *qpos, void *qvel, void *qacc_ws, void *tau, void *dv,
-               void *f, int32_t *status, void *obs, void *frames, int32_t *ncon, int32_t *con_pairs,
+               void *f, int32_t *status, void *obs, int obs_ld, void *frames, int32_t *ncon, int32_t *con_pairs,
                int32_t *info, int n_substeps, void *stream);
 
 /* walking reference update for every env, on the device (config 3): what the reference's main.py:117
@@ -108,10 +115,12 @@ int tsidb_step(tsidb_handle h, void *q, void *v, void *qpos, void *qvel, void *q
  * k occupies [t_start + k T, t_start + (k+1) T); afterwards both feet are down.  Writes the registered
  * foot_ref / contact_ref / contact_active / com_ref (position, velocity, acceleration) buffers; contact
  * on/off edges re-reference at `frames` [N,2,12] (current sole placements from the last tsidb_tick), as
- * ctrl/WalkController.py:215-253 intends. */
+ * ctrl/WalkController.py:215-253 intends.  t_offset [N] (may be NULL) delays each env's timeline: env e runs
+ * on the clock max(t - t_offset[e], 0), so that the envs of one batch need not step in phase. */
 int tsidb_walk_update(tsidb_handle h, const void *coef, const int32_t *side, const int32_t *nsteps,
                       const void *rest, const void *com, int K, double t, double step_duration, double t_start,
-                      double omega, double com_z0, double com_drop, const void *frames, void *stream);
+                      double omega, double com_z0, double com_drop, const void *frames, const void *t_offset,
+                      void *stream);
 
 /* probe of formulation.computeProblemData's rigid-body terms (main.py:119): M [N,26,26],
  * hbias [N,26], Jcom [N,3,26], Jf [N,2,6,26] (LOCAL), oMf [N,2,12], com [N,3].  Test/debug use. */

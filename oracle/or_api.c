@@ -27,11 +27,27 @@ static void sim_to_tsid(const OrModel *m, const double *qpos, const double *qvel
   }
 }
 
+extern __thread double or_last_frames[24], or_last_rowx[2];
+
 int or_env_step_batch_env(const OrModel *m, const double *params, int n, double *q, double *v, double *qpos,
                           double *qvel, double *qacc_ws, const double *com_ref, const double *posture_ref,
                           const double *foot_ref, const double *contact_ref, const uint8_t *contact_active,
                           const double *cop_frames, const double *env_params, double *tau, double *dv, double *f,
                           int32_t *status, double *obs, int32_t *ncon, int32_t *con_geom, int nthreads) {
+  return or_env_step_batch_walk(m, params, n, q, v, qpos, qvel, qacc_ws, (double *)com_ref, posture_ref, (double *)foot_ref,
+                                (double *)contact_ref, (uint8_t *)contact_active, cop_frames, env_params, tau, dv, f, status, obs,
+                                ncon, con_geom, nthreads, NULL, NULL, NULL);
+}
+
+/* the same env step preceded, per env, by the walking reference update of or_walk.c when `w` is given (the
+ * config-3 workload: what bench.py's GPU loop does with tsidb_walk_update + tsidb_tick + tsidb_sim); `frames`
+ * [n,2,12] carries the sole placements from one tick to the next update, as on the device */
+int or_env_step_batch_walk(const OrModel *m, const double *params, int n, double *q, double *v, double *qpos,
+                           double *qvel, double *qacc_ws, double *com_ref, const double *posture_ref,
+                           double *foot_ref, double *contact_ref, uint8_t *contact_active,
+                           const double *cop_frames, const double *env_params, double *tau, double *dv, double *f,
+                           int32_t *status, double *obs, int32_t *ncon, int32_t *con_geom, int nthreads,
+                           const OrWalkTables *w, double *frames, double *rewdone) {
   const int sim = params[P_SIM_ENABLED] != 0.0;
   const int closed = params[P_CLOSED_LOOP] != 0.0;
   const int quirks = params[P_QUIRKS] != 0.0 && !closed;
@@ -41,12 +57,20 @@ int or_env_step_batch_env(const OrModel *m, const double *params, int n, double 
 #endif
   for (int e = 0; e < n; e++) {
     double *qe = q + (size_t)e * OR_NQ, *ve = v + (size_t)e * OR_NV;
+    if (w)
+      or_walk_update(1, w->coef + (size_t)e * w->K * 16, w->side + (size_t)e * w->K, w->nsteps + e,
+                     w->rest + (size_t)e * (w->K + 1) * 8, w->com + (size_t)e * (w->K + 2) * 6, w->K, w->t,
+                     w->t_off ? w->t_off + e : NULL, w->T, w->t_start, w->omega, w->z0, w->dz, frames + (size_t)e * 24,
+                     foot_ref + (size_t)e * 48, contact_ref + (size_t)e * 24, contact_active + (size_t)e * 2,
+                     com_ref + (size_t)e * 9);
     if (closed) sim_to_tsid(m, qpos + (size_t)e * OR_NQ, qvel + (size_t)e * OR_NV, qe, ve);
     int st = or_tsid_tick(m, params, qe, ve, com_ref + (size_t)e * 9, posture_ref + (size_t)e * OR_NA,
                           foot_ref + (size_t)e * 48, contact_ref + (size_t)e * 24, contact_active + (size_t)e * 2,
                           cop_frames ? cop_frames + (size_t)e * 24 : NULL, tau + (size_t)e * OR_NA,
                           dv + (size_t)e * OR_NV, f + (size_t)e * 24, obs ? obs + (size_t)e * OR_NOBS : NULL, NULL);
     status[e] = st;
+    if (frames && st != 4) memcpy(frames + (size_t)e * 24, or_last_frames, sizeof or_last_frames);
+    if (rewdone) { rewdone[2 * (size_t)e] = or_last_rowx[0]; rewdone[2 * (size_t)e + 1] = or_last_rowx[1]; }
     if (!sim) continue;
     double *qp = qpos + (size_t)e * OR_NQ, *qv = qvel + (size_t)e * OR_NV;
     double ctrl[OR_NA] = {0};

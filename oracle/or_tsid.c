@@ -462,6 +462,14 @@ done:
 }
 
 /* ================================================================= tick */
+/* sole placements (R row-major 9 + p 3, per foot) of the last or_tsid_tick on this thread: what the device tick
+ * writes to `frames` (the data of this tick's computeProblemData, before integration) */
+__thread double or_last_frames[24];
+/* reward and done flag of the last or_tsid_tick on this thread (SURVEY.md 8d write list; no reference
+ * counterpart): reward = exp(-|com - com_ref|^2 / sigma^2) - c_tau |tau|^2 on this tick's data, done = failed QP,
+ * base lower than DONE_HEIGHT or base z-axis . world z below DONE_TILT at the new state */
+__thread double or_last_rowx[2];
+
 int or_tsid_tick(const OrModel *m, const double *params, double *q, double *v, const double *com_ref,
                  const double *posture_ref, const double *foot_ref, const double *contact_ref,
                  const uint8_t *contact_active, const double *cop_frames, double *tau, double *dv,
@@ -479,10 +487,12 @@ int or_tsid_tick(const OrModel *m, const double *params, double *q, double *v, c
     for (int i = 0; i < 24; i++) chk += fabs(contact_ref[i]);
     if (!(chk <= 1e300)) {
       if (iters) *iters = 0;
+      or_last_rowx[0] = 0.0; or_last_rowx[1] = 1.0;
       return 4;
     }
   }
   or_rbd_terms(m, q, v, &t);
+  memcpy(or_last_frames, t.oMf, sizeof or_last_frames);
   or_tsid_assemble(m, params, &t, q, v, com_ref, posture_ref, foot_ref, contact_ref, contact_active, &qp);
   int status = or_qp_solve(&qp, (int)params[P_MAX_ITER], &sol);
   if (iters) *iters = sol.iter;
@@ -542,6 +552,16 @@ int or_tsid_tick(const OrModel *m, const double *params, double *q, double *v, c
   if (obs) {
     memcpy(obs, q, OR_NQ * sizeof(double));
     memcpy(obs + OR_NQ, v, OR_NV * sizeof(double));
+  }
+  or_last_rowx[0] = 0.0; or_last_rowx[1] = 1.0;
+  if (status == 0) {
+    const double up = 1.0 - 2.0 * (q[3] * q[3] + q[4] * q[4]);
+    const int fall = q[2] < params[P_DONE_HEIGHT] || up < params[P_DONE_TILT];
+    double e2 = 0, tau2 = 0;
+    for (int i = 0; i < 3; i++) e2 += (t.com[i] - com_ref[i]) * (t.com[i] - com_ref[i]);
+    for (int i = 0; i < OR_NA; i++) tau2 += tau[i] * tau[i];
+    or_last_rowx[1] = fall ? 1.0 : 0.0;
+    or_last_rowx[0] = fall ? 0.0 : exp(-e2 / (params[P_REW_SIGMA] * params[P_REW_SIGMA])) - params[P_REW_CTAU] * tau2;
   }
   return status;
 }

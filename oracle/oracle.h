@@ -29,7 +29,8 @@ enum {
   P_HESS_REG, P_QUIRKS, P_NORMAL /*3*/, P_CPOINTS = P_NORMAL + 3 /*12*/,
   P_KP_POSTURE = P_CPOINTS + 12 /*20*/, P_KD_POSTURE = P_KP_POSTURE + 20,
   P_TAU_MAX = P_KD_POSTURE + 20, P_V_MAX = P_TAU_MAX + 20, P_MAX_ITER = P_V_MAX + 20,
-  P_SIM_ENABLED, P_CLOSED_LOOP, P_W_AM, P_KP_AM /*3*/, P_COUNT = 128
+  P_SIM_ENABLED, P_CLOSED_LOOP, P_W_AM, P_KP_AM /*3*/, P_REW_SIGMA = P_KP_AM + 3, P_REW_CTAU, P_DONE_HEIGHT, P_DONE_TILT,
+  P_SELF_COLLISION, P_W_COP, P_COUNT = 128
 };
 
 typedef struct {
@@ -137,6 +138,28 @@ int or_env_step_batch_env(const OrModel *m, const double *params, int n, double 
                           const double *cop_frames, const double *env_params /* [n][8] or NULL */, double *tau,
                           double *dv, double *f, int32_t *status, double *obs, int32_t *ncon, int32_t *con_geom,
                           int nthreads);
+
+/* walking reference update for one tick (or_walk.c): the device kernel behind tsidb_walk_update, restated from
+ * ctrl/Foot_Trajectory.py:21-27, ctrl/Walk_Planner.py:23-31, ctrl/WalkController.py:189-253, ctrl/LIPM.py:34-49 */
+void or_walk_update(int n, const double *coef, const int32_t *side, const int32_t *nsteps, const double *rest,
+                    const double *com, int K, double t, const double *t_off, double T, double t_start, double omega,
+                    double z0, double dz, const double *frames, double *foot_ref, double *contact_ref,
+                    uint8_t *contact_active, double *com_ref);
+
+/* walking tables for or_env_step_batch_walk (env-major, layouts as or_walk_update) */
+typedef struct {
+  const double *coef, *rest, *com, *t_off;
+  const int32_t *side, *nsteps;
+  int K;
+  double t, T, t_start, omega, z0, dz;
+} OrWalkTables;
+int or_env_step_batch_walk(const OrModel *m, const double *params, int n, double *q, double *v, double *qpos,
+                           double *qvel, double *qacc_ws, double *com_ref, const double *posture_ref,
+                           double *foot_ref, double *contact_ref, uint8_t *contact_active,
+                           const double *cop_frames, const double *env_params, double *tau, double *dv, double *f,
+                           int32_t *status, double *obs, int32_t *ncon, int32_t *con_geom, int nthreads,
+                           const OrWalkTables *w /* NULL: references as given */, double *frames /* [n,2,12] or NULL */,
+                           double *rewdone /* [n,2] reward, done; or NULL */);
 
 #ifdef __cplusplus
 }

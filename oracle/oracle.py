@@ -41,6 +41,33 @@ class OrSimInfo(C.Structure):
                 ("qfrc_bias", C.c_double * NV), ("qfrc_actuator", C.c_double * NV), ("M", C.c_double * (NV * NV))]
 
 
+class OrWalkTables(C.Structure):
+    _fields_ = [("coef", C.c_void_p), ("rest", C.c_void_p), ("com", C.c_void_p), ("t_off", C.c_void_p),
+                ("side", C.c_void_p), ("nsteps", C.c_void_p), ("K", C.c_int), ("t", C.c_double), ("T", C.c_double),
+                ("t_start", C.c_double), ("omega", C.c_double), ("z0", C.c_double), ("dz", C.c_double)]
+
+
+class WalkTables:
+    """numpy copies of a WalkSchedule's tables (first n envs) in the layout or_env_step_batch_walk reads"""
+
+    def __init__(self, sched, n=None):
+        n = sched.N if n is None else n
+        g = lambda x: np.ascontiguousarray(x[:n].detach().cpu().numpy(), dtype=np.float64)
+        self.keep = dict(coef=g(sched.coef), rest=g(sched.rest), com=g(sched.com),
+                         side=np.ascontiguousarray(sched.side[:n].cpu().numpy(), dtype=np.int32),
+                         nsteps=np.ascontiguousarray(sched.nsteps[:n].cpu().numpy(), dtype=np.int32),
+                         t_off=g(sched.t_offset) if getattr(sched, "t_offset", None) is not None else None)
+        k = self.keep
+        self.c = OrWalkTables(k["coef"].ctypes.data, k["rest"].ctypes.data, k["com"].ctypes.data,
+                              k["t_off"].ctypes.data if k["t_off"] is not None else None, k["side"].ctypes.data,
+                              k["nsteps"].ctypes.data, sched.K, 0.0, float(sched.conf.step_duration),
+                              float(sched.t_start), float(sched.omega), float(sched.z0), float(sched.dz))
+
+    def at(self, t):
+        self.c.t = float(t)
+        return self
+
+
 def build(force=False):
     so = HERE / "liboracle.so"
     srcs = list(HERE.glob("*.c")) + [HERE / "oracle.h"]
@@ -66,9 +93,10 @@ class Oracle:
         self.lib = L = C.CDLL(str(so))
         L.or_model_load.restype = C.c_void_p
         L.or_model_load.argtypes = [C.c_char_p, C.c_size_t]
-        for name in ("or_model_free", "or_rbd_terms", "or_rnea", "or_integrate", "or_log6", "or_tsid_assemble"):
+        for name in ("or_model_free", "or_rbd_terms", "or_rnea", "or_integrate", "or_log6", "or_tsid_assemble", "or_walk_update"):
             getattr(L, name).restype = None
-        for name in ("or_qp_solve", "or_tsid_tick", "or_sim_step", "or_sim_step_env", "or_env_step_batch", "or_env_step_batch_env"):
+        for name in ("or_qp_solve", "or_tsid_tick", "or_sim_step", "or_sim_step_env", "or_env_step_batch", "or_env_step_batch_env",
+                     "or_env_step_batch_walk"):
             getattr(L, name).restype = C.c_int
         self.m = C.c_void_p(L.or_model_load(blob_bytes, len(blob_bytes)))
         if not self.m:
@@ -159,17 +187,41 @@ class Oracle:
                     M=np.array(info.M).reshape(NV, NV))
 
     # ---- batch env step (all arrays float64, env-major, updated in place)
-    def env_step_batch(self, params, st, nthreads=1):
+    def env_step_batch(self, params, st, nthreads=1, walk=None):
+        """walk = WalkTables.at(t): the walking reference update (or_walk.c) runs per env before its tick, with
+        st["frames"] [n,2,12] carrying the sole placements between ticks (the config-3 workload)."""
         n = st["q"].shape[0]
         params = _f64(params)
         cf = st.get("cop_frames")
         ep = st.get("env_params")
-        self.lib.or_env_step_batch_env(
+        fr = st.get("frames")
+        rd = st.get("rewdone")
+        if walk is not None and fr is None:
+            raise ValueError("walking env step needs st['frames']")
+        self.lib.or_env_step_batch_walk(
             self.m, _p(params), n, _p(st["q"]), _p(st["v"]), _p(st["qpos"]), _p(st["qvel"]), _p(st["qacc_ws"]),
             _p(st["com_ref"]), _p(st["posture_ref"]), _p(st["foot_ref"]), _p(st["contact_ref"]),
             _p(st["contact_active"]), _p(cf) if cf is not None else None, _p(ep) if ep is not None else None,
             _p(st["tau"]), _p(st["dv"]), _p(st["f"]),
-            _p(st["status"]), _p(st["obs"]), _p(st["ncon"]), _p(st["con_geom"]), int(nthreads))
+            _p(st["status"]), _p(st["obs"]), _p(st["ncon"]), _p(st["con_geom"]), int(nthreads),
+            C.byref(walk.c) if walk is not None else None, _p(fr) if fr is not None else None,
+            _p(rd) if rd is not None else None)
+
+
+def walk_update(lib, sched, t, frames, foot_ref, contact_ref, contact_active, com_ref):
+    """or_walk_update on numpy copies of a WalkSchedule's tables; the four reference arrays are updated in place."""
+    g = lambda x: _f64(x.detach().cpu().numpy())
+    coef, rest, com = g(sched.coef), g(sched.rest), g(sched.com)
+    side = np.ascontiguousarray(sched.side.cpu().numpy(), dtype=np.int32)
+    nsteps = np.ascontiguousarray(sched.nsteps.cpu().numpy(), dtype=np.int32)
+    toff = g(sched.t_offset) if getattr(sched, "t_offset", None) is not None else None
+    frames = _f64(frames)
+    lib.or_walk_update.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_double,
+                                   C.c_void_p] + [C.c_double] * 5 + [C.c_void_p] * 5
+    lib.or_walk_update(sched.N, _p(coef), _p(side), _p(nsteps), _p(rest), _p(com), sched.K, float(t),
+                       _p(toff) if toff is not None else None, float(sched.conf.step_duration), float(sched.t_start),
+                       float(sched.omega), float(sched.z0), float(sched.dz), _p(frames), _p(foot_ref), _p(contact_ref),
+                       _p(contact_active), _p(com_ref))
 
 
 def new_state(n):
@@ -179,4 +231,4 @@ def new_state(n):
                 posture_ref=z(n, NA), foot_ref=z(n, 2, 24), contact_ref=z(n, 2, 12),
                 contact_active=np.ones((n, 2), dtype=np.uint8), cop_frames=z(n, 2, 12), tau=z(n, NA), dv=z(n, NV),
                 f=z(n, 24), status=np.zeros(n, dtype=np.int32), obs=z(n, NOBS), ncon=np.zeros(n, dtype=np.int32),
-                con_geom=np.zeros((n, MAXCON), dtype=np.int32))
+                con_geom=np.zeros((n, MAXCON), dtype=np.int32), rewdone=z(n, 2))

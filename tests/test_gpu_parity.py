@@ -115,6 +115,7 @@ def test_env_loop_f64_matches_oracle(oracle, sim):
         assert np.abs(wrench(wc.f.cpu().numpy(), wc.params) - wrench(st["f"], wc.params)).max() < 1e-7, i
         assert diff(wc.q, st["q"]) < 1e-9 and diff(wc.v, st["v"]) < 1e-9, i
         assert diff(wc.obs, st["obs"]) < 1e-7, i
+        assert diff(wc.rows[:, 65:], st["rewdone"]) < 1e-9, i                       # reward, done
         if sim:
             assert np.array_equal(wc.ncon.cpu().numpy(), st["ncon"]), i
             assert np.array_equal(wc.con_pairs.cpu().numpy(), st["con_geom"]), i      # integer contact indexing bit-exact
@@ -475,12 +476,23 @@ def test_api_error_behaviour():
     assert rc != 0 and b"TSIDBM01" in L.tsidb_last_error(h)
     L.tsidb_destroy(h)
     wc = make(2)
+    # truncated / corrupt blobs are rejected before anything is read past the buffer
+    raw = wc.model.raw
+    for cut in (20, 16 + 40 * 3, len(raw) // 2, len(raw) - 8):
+        rc = L.tsidb_create(raw[:cut], cut, wc.params.ctypes.data_as(C.c_void_p), P_COUNT, 4, 0, 0, C.byref(h))
+        assert rc != 0 and b"model blob" in L.tsidb_last_error(h), cut
+        L.tsidb_destroy(h)
+    bad = bytearray(raw)
+    bad[16 + 24 + 4:16 + 24 + 8] = (0x7fffffff).to_bytes(4, "little")  # first section's count
+    rc = L.tsidb_create(bytes(bad), len(bad), wc.params.ctypes.data_as(C.c_void_p), P_COUNT, 4, 0, 0, C.byref(h))
+    assert rc != 0 and b"bad section" in L.tsidb_last_error(h)
+    L.tsidb_destroy(h)
     rc = L.tsidb_create(wc.model.raw, len(wc.model.raw), wc.params.ctypes.data_as(C.c_void_p), P_COUNT, 4, 99, 0, C.byref(h))
     assert rc != 0 and b"device" in L.tsidb_last_error(h)
     L.tsidb_destroy(h)
     rc = L.tsidb_create(wc.model.raw, len(wc.model.raw), wc.params.ctypes.data_as(C.c_void_p), P_COUNT, 4, 0, 0, C.byref(h))
     assert rc == 0
-    rc = L.tsidb_tick(h, None, None, None, None, None, None, None, None, None, None)
+    rc = L.tsidb_tick(h, None, None, None, None, None, None, None, 65, None, None, None)
     assert rc != 0 and b"tsidb_set_refs" in L.tsidb_last_error(h)   # references never registered
     L.tsidb_destroy(h)
 
@@ -579,3 +591,156 @@ def test_step_pipelined_equals_step():
     c = make(4, closed_loop=True)
     with pytest.raises(Exception, match="step_pipelined"):
         c.step_pipelined()
+
+
+def test_step_pipelined_mixed_with_reset_and_env_params():
+    """reset() / step() / sim_step() / set_env_params() wait for the sim stage that
+    step_pipelined() left on the side stream - mixing the entry points (the RL pattern: partial reset
+    between pipelined steps) gives the serial path's results bit for bit."""
+    a, b = make(96, reference_quirks=False), make(96, reference_quirks=False)
+    perturb(a, 7); perturb(b, 7)
+    ids = [3, 17, 64, 95]
+    fr = torch.linspace(0.5, 1.0, 96, dtype=torch.float64)
+    for k in range(30):
+        a.step()
+        b.step_pipelined()
+        if k % 7 == 6:
+            a.reset(env_ids=ids)
+            b.reset(env_ids=ids)
+        if k == 12:
+            a.set_env_params(friction=fr)
+            b.set_env_params(friction=fr)
+        if k == 20:
+            a.step()
+            b.step()  # a serial step right after a pipelined one
+    b.sync_sim()
+    torch.cuda.synchronize()
+    for k in ("q", "v", "tau", "dv", "f", "status", "obs", "qpos", "qvel", "qacc_warmstart", "ncon", "con_pairs", "info"):
+        assert torch.equal(getattr(a, k), getattr(b, k)), k
+
+
+@pytest.mark.parametrize("dephase", [False, True])
+def test_walk_update_kernel_matches_oracle_restatement(oracle, dephase):
+    """f-2's independent check: tsidb_walk_update (k_walk) against oracle/or_walk.c - a C restatement of
+    the same reference semantics (Foot_Trajectory.py:21-27 polynomials, Walk_Planner.py:23-31 swings,
+    WalkController.py:189-253 contact edges, LIPM.py:34-49 in closed form) that shares no code with the
+    kernel or with WalkSchedule.sample().  Contact flags bit-exact, references to 1e-12, over the start
+    phase, every contact edge of the first steps and the final stand; also with per-env start delays."""
+    from oracle.oracle import walk_update
+    from tsid_control_amd.walk_planner import WalkSchedule
+    n = 24
+    wc = make(n, sim_enabled=False, walking=True)
+    lf, rf = wc.frames[0, 0, 9:11].cpu().numpy(), wc.frames[0, 1, 9:11].cpu().numpy()
+    sched = WalkSchedule.from_demo_paths(n, wc.conf, wc.device, wc.dtype, seed=5, q0_feet=(lf, rf), t_start=0.25)
+    if dephase:
+        sched.set_phase_offsets(torch.linspace(0.0, 0.9, n, dtype=torch.float64))
+    npy = lambda x: np.ascontiguousarray(x.cpu().numpy())
+    ticks = list(range(0, 900, 3)) + list(range(5000, 5400, 9))   # the second block is past every env's last step
+    for i in ticks:
+        t = i * wc.conf.dt
+        fr, cr, ca, cm = npy(wc.foot_ref), npy(wc.contact_ref), npy(wc.contact_active), npy(wc.com_ref)
+        walk_update(oracle.lib, sched, t, npy(wc.frames), fr, cr, ca, cm)
+        sched.apply(wc, t)
+        assert np.array_equal(npy(wc.contact_active), ca), i
+        assert diff(wc.foot_ref, fr) < 1e-12 and diff(wc.contact_ref, cr) < 1e-12 and diff(wc.com_ref, cm) < 1e-12, i
+        wc.tick()   # moves the feet, so the next edge re-references at a new placement
+    assert int((wc.status != 0).sum()) == 0
+
+
+def test_golden_foot_trajectories_through_the_device_kernel():
+    """Pins the DEVICE evaluation of a12 to the reference itself: the five FootTrajectory cases of
+    tests/golden/planners.json (generated by importing /root/reference/ctrl/Foot_Trajectory.py, see
+    make_planner_golden.py) go through tsidb_walk_update's polynomial path as one-step schedules; the
+    foot-task reference the kernel writes equals the reference's get_position() to 1e-11, and its
+    acceleration slot equals the reference's get_velocity() (which is the 2nd derivative, quirk F6f)."""
+    import json
+    from pathlib import Path
+    from tsid_control_amd.foot_trajectory import FootTrajectory
+    from tsid_control_amd.walk_planner import WalkSchedule
+    gold = json.loads((Path(__file__).parent / "golden" / "planners.json").read_text())["foot_traj"]
+    for case in gold:
+        p = case["params"]
+        t0, t1 = p["t"]
+        wc = make(1, sim_enabled=False)
+        start, target = list(map(float, p["start"])), list(map(float, p["target"]))
+        tr = FootTrajectory([t0, t1], start, target, p["h"], p["rise"])
+        # a hand-made one-step table: step 0 swings the left foot along this trajectory
+        sched = WalkSchedule.__new__(WalkSchedule)
+        sched.conf = type("C", (), {"step_duration": t1 - t0})()
+        sched.N, sched.K, sched.device, sched.dtype, sched.t_offset = 1, 1, wc.device, wc.dtype, None
+        sched.t_start, sched.omega, sched.z0, sched.dz = 0.0, 3.0, 0.24, 0.0
+        dev = lambda a, dt=wc.dtype: torch.as_tensor(np.asarray(a), device=wc.device).to(dt)
+        sched.coef = dev(tr.coefficients()[None, None])
+        sched.side, sched.nsteps = dev([[0]], torch.long), dev([1], torch.long)
+        sched.rest = dev(np.zeros((1, 2, 2, 4)))
+        sched.com = dev(np.zeros((1, 3, 2, 3)))
+        for i, t in enumerate(case["ts"]):
+            if t >= t1:
+                continue   # the step is over at t1: the foot is back on its rest pose
+            sched.apply(wc, t - t0)
+            fr = wc.foot_ref[0, 0].cpu().numpy()
+            if i == 0:
+                continue   # the tick that lifts the foot re-references at the current placement (remove_contact)
+            assert np.allclose(fr[:3], case["pos"][i], atol=1e-11), (p, t)
+            assert np.allclose(fr[18:21], case["vel"][i], atol=1e-8), (p, t)   # reference "velocity" = 2nd derivative
+            if "yaw" in case:
+                assert abs(np.arctan2(fr[4], fr[3]) - case["yaw"][i]) < 1e-11
+
+
+def test_walking_env_loop_matches_oracle_walk(oracle):
+    """Config 3 in small, end to end against the oracle's OWN walking update (or_walk.c inside
+    or_env_step_batch_walk): k_walk + k_tick + k_sim on the device, walk update + tick + sim step on the CPU,
+    each side producing its own references from the same tables - start phase, first lift-off, several
+    single-support steps with touch-down / lift-off edges; de-phased so that 50- and 38-variable QPs mix."""
+    from oracle.oracle import WalkTables
+    from tsid_control_amd.walk_planner import WalkSchedule, op3_walking_posture
+    n = 12
+    wc = make(n, walking=True, reference_quirks=False)
+    wc.posture_ref += torch.as_tensor(op3_walking_posture(), device=wc.device)
+    lf, rf = wc.frames[0, 0, 9:11].cpu().numpy(), wc.frames[0, 1, 9:11].cpu().numpy()
+    sched = WalkSchedule.from_demo_paths(n, wc.conf, wc.device, wc.dtype, seed=4, q0_feet=(lf, rf),
+                                         com0=wc.com_ref[0, :3].cpu().numpy(), t_start=0.4)
+    sched.set_phase_offsets(torch.linspace(0.0, 0.5, n, dtype=torch.float64))
+    st = mirror(wc)
+    st["frames"] = wc.frames.cpu().numpy().copy()
+    tables = WalkTables(sched)
+    mixed = 0
+    for i in range(900):
+        t = i * wc.conf.dt
+        sched.apply(wc, t)
+        wc.step()
+        oracle.env_step_batch(wc.params, st, nthreads=8, walk=tables.at(t))
+        assert np.array_equal(wc.contact_active.cpu().numpy(), st["contact_active"]), i
+        assert np.array_equal(wc.status.cpu().numpy(), st["status"]), i
+        ns = wc.contact_active.sum(dim=1)
+        mixed += int(ns.min() != ns.max())
+        if i % 25 == 0 or i == 899:
+            assert diff(wc.tau, st["tau"]) < 1e-6 and diff(wc.dv, st["dv"]) < 1e-5, i
+            assert diff(wc.q, st["q"]) < 1e-8 and diff(wc.v, st["v"]) < 1e-7, i
+            assert diff(wc.com_ref, st["com_ref"]) < 1e-12 and diff(wc.foot_ref, st["foot_ref"]) < 1e-8, i
+            assert diff(wc.qpos, st["qpos"]) < 1e-8, i
+            assert np.array_equal(wc.ncon.cpu().numpy(), st["ncon"]), i
+    assert mixed > 100 and int((wc.status != 0).sum()) == 0
+
+
+def test_reward_and_done_outputs(oracle):
+    """reward[N], done[N] (SURVEY.md 8d write list; no reference counterpart) ride in columns 65, 66 of the
+    per-env row: tracking reward minus torque cost; done = failed QP / non-finite input / base too low / tilted."""
+    n = 8
+    wc = make(n, sim_enabled=False)
+    perturb(wc, 11)
+    wc.q[1, 2] = 0.15                                        # base below done_base_height (0.2 m)
+    ang = np.deg2rad(60.0)                                   # tilted by 60 deg about x (limit 45 deg)
+    wc.q[2, 3:7] = torch.tensor([np.sin(ang / 2), 0.0, 0.0, np.cos(ang / 2)], dtype=wc.dtype, device=wc.device)
+    wc.q[3, 9] = float("nan")
+    st = mirror(wc)
+    wc.step()
+    oracle.env_step_batch(wc.params, st, nthreads=4)
+    rd = wc.rows[:, 65:].cpu().numpy()
+    assert np.array_equal(wc.status.cpu().numpy(), st["status"])
+    assert np.allclose(rd, st["rewdone"], atol=1e-9)
+    assert rd[1, 1] == 1 and rd[2, 1] == 1 and rd[3, 1] == 1 and rd[3, 0] == 0
+    ok = [0, 4, 5, 6, 7]
+    assert np.all(rd[ok, 1] == 0) and np.all(rd[ok, 0] > 0.5) and np.all(rd[ok, 0] < 1.0)
+    assert torch.equal(wc.reward, wc.rows[:, 65]) and torch.equal(wc.done, wc.rows[:, 66])
+    assert wc.gather_rows().shape == (n, 67) and wc.gather_rows().is_contiguous()

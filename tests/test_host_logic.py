@@ -83,3 +83,18 @@ def test_product_never_imports_oracle():
         if f.suffix in (".py", ".hip", ".hpp", ".h"):
             txt = f.read_text()
             assert "oracle" not in txt.replace("no oracle", "").lower() or f.name == "model_compiler.py", f
+
+
+def test_truncated_model_blob_is_rejected_on_the_host(blob):
+    """tsidb_create validates the section table before any HIP call: a truncated or corrupt blob gives an
+    error message, never a read past the buffer (no GPU needed - the check precedes device selection)."""
+    from tsid_control_amd import _lib
+    from tsid_control_amd.params import P_COUNT
+    L = _lib.load()
+    p = np.zeros(P_COUNT)
+    raw = blob.raw
+    for cut in (20, 16 + 40 * 3, len(raw) // 2, len(raw) - 8):
+        h = ctypes.c_void_p()
+        rc = L.tsidb_create(raw[:cut], cut, p.ctypes.data_as(ctypes.c_void_p), P_COUNT, 4, 0, 0, ctypes.byref(h))
+        assert rc != 0 and b"model blob" in L.tsidb_last_error(h), cut
+        L.tsidb_destroy(h)

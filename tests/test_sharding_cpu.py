@@ -56,10 +56,10 @@ def _worker(rank, world, port, n_total, steps, out_dir):
     sizes = [shard_range(n_total, i, w)[1] - shard_range(n_total, i, w)[0] for i in range(w)]
     lo, hi = shard_range(n_total, r, w)
     mine = _slice(st, lo, hi)
-    gather = ObsGather(hi - lo, 65, w, torch.float64, "cpu", sizes=sizes)
+    gather = ObsGather(hi - lo, 67, w, torch.float64, "cpu", sizes=sizes)   # obs[65] + reward + done per env
     for _ in range(steps):
         orc.env_step_batch(P, mine)
-        gather(torch.from_numpy(mine["obs"]))
+        gather(torch.from_numpy(np.concatenate([mine["obs"], mine["rewdone"]], axis=1)))
     if r == 0:
         np.save(Path(out_dir) / "gathered.npy", gather.out.numpy())
     torch.distributed.barrier()
@@ -84,8 +84,9 @@ def test_world2_gloo_gather_equals_single_process(tmp_path):
     orc, P, st = _initial_state(n_total)
     for _ in range(steps):
         orc.env_step_batch(P, st)
-    assert got.shape == (n_total, 65)
-    assert np.array_equal(got, st["obs"])          # bit-identical: envs never interact
+    assert got.shape == (n_total, 67)
+    assert np.array_equal(got[:, :65], st["obs"])          # bit-identical: envs never interact
+    assert np.array_equal(got[:, 65:], st["rewdone"]) and np.all(got[:, 66] == 0) and np.all(got[:, 65] > 0)
 
 
 def test_world3_ragged_shards(tmp_path):
@@ -96,4 +97,4 @@ def test_world3_ragged_shards(tmp_path):
     orc, P, st = _initial_state(n_total)
     for _ in range(steps):
         orc.env_step_batch(P, st)
-    assert np.array_equal(got, st["obs"])
+    assert np.array_equal(got, np.concatenate([st["obs"], st["rewdone"]], axis=1))

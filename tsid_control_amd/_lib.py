@@ -36,13 +36,13 @@ def load():
     L.tsidb_set_params.argtypes = [vp, vp, C.c_int]
     L.tsidb_set_refs.argtypes = [vp] * 7
     L.tsidb_reset.argtypes = [vp, i32p, C.c_int, vp, vp, vp, vp, vp, vp]
-    L.tsidb_tick.argtypes = [vp] * 11
+    L.tsidb_tick.argtypes = [vp] * 8 + [C.c_int] + [vp] * 3
     L.tsidb_sim.argtypes = [vp] * 11
-    L.tsidb_step.argtypes = [vp] * 15 + [C.c_int, vp]
+    L.tsidb_step.argtypes = [vp] * 11 + [C.c_int] + [vp] * 4 + [C.c_int, vp]
     L.tsidb_rbd_terms.argtypes = [vp] * 10
     L.tsidb_lds_bytes.argtypes = [C.c_int, C.c_int]
     L.tsidb_set_env_params.argtypes = [vp, vp]
-    L.tsidb_walk_update.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int] + [C.c_double] * 6 + [vp, vp]
+    L.tsidb_walk_update.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int] + [C.c_double] * 6 + [vp, vp, vp]
     for s in SYMBOLS:
         if s != "tsidb_last_error":
             getattr(L, s).restype = C.c_int

@@ -24,7 +24,7 @@ template <typename T>
 __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2))) void k_tick(const DevModel<T> *__restrict__ mp, int n, T *q, T *v, const T *com_ref,
                                                   const T *posture_ref, const T *foot_ref, const T *contact_ref,
                                                   const uint8_t *cact, const T *cop_frames, T *tau, T *dv, T *f,
-                                                  int *status, T *obs, T *frames, int *info, const T *qpos_sim,
+                                                  int *status, T *obs, int obs_ld, T *frames, int *info, const T *qpos_sim,
                                                   const T *qvel_sim) {
   __shared__ TickLds<T> L;
   const int e = blockIdx.x, lane = threadIdx.x;
@@ -46,6 +46,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2))) void 
       if (lane == 0) {
         status[e] = 4;
         if (info) { info[E * 4] = 0; info[E * 4 + 1] = 0; }
+        if (obs && obs_ld >= NROW) { obs[E * obs_ld + NOBS] = 0; obs[E * obs_ld + NOBS + 1] = 1; }
       }
       return;
     }
@@ -53,17 +54,17 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2))) void 
   if (ns == 2) {
     tsid_tick_env<T, 2>(*mp, L, lane, q + E * NQ, v + E * NV, com_ref + E * 9, posture_ref + E * NA, foot_ref + E * 48,
                          contact_ref + E * 24, cact + E * 2, cop_frames ? cop_frames + E * 24 : nullptr, tau + E * NA,
-                         dv + E * NV, f + E * 24, status + e, obs ? obs + E * NOBS : nullptr, info ? info + E * 4 : nullptr,
+                         dv + E * NV, f + E * 24, status + e, obs ? obs + E * obs_ld : nullptr, (obs && obs_ld >= NROW) ? obs + E * obs_ld + NOBS : nullptr, info ? info + E * 4 : nullptr,
                          qpos_sim ? qpos_sim + E * NQ : nullptr, qvel_sim ? qvel_sim + E * NV : nullptr);
   } else if (ns == 1) {
     tsid_tick_env<T, 1>(*mp, L, lane, q + E * NQ, v + E * NV, com_ref + E * 9, posture_ref + E * NA, foot_ref + E * 48,
                          contact_ref + E * 24, cact + E * 2, cop_frames ? cop_frames + E * 24 : nullptr, tau + E * NA,
-                         dv + E * NV, f + E * 24, status + e, obs ? obs + E * NOBS : nullptr, info ? info + E * 4 : nullptr,
+                         dv + E * NV, f + E * 24, status + e, obs ? obs + E * obs_ld : nullptr, (obs && obs_ld >= NROW) ? obs + E * obs_ld + NOBS : nullptr, info ? info + E * 4 : nullptr,
                          qpos_sim ? qpos_sim + E * NQ : nullptr, qvel_sim ? qvel_sim + E * NV : nullptr);
   } else {
     tsid_tick_env<T, 0>(*mp, L, lane, q + E * NQ, v + E * NV, com_ref + E * 9, posture_ref + E * NA, foot_ref + E * 48,
                          contact_ref + E * 24, cact + E * 2, cop_frames ? cop_frames + E * 24 : nullptr, tau + E * NA,
-                         dv + E * NV, f + E * 24, status + e, obs ? obs + E * NOBS : nullptr, info ? info + E * 4 : nullptr,
+                         dv + E * NV, f + E * 24, status + e, obs ? obs + E * obs_ld : nullptr, (obs && obs_ld >= NROW) ? obs + E * obs_ld + NOBS : nullptr, info ? info + E * 4 : nullptr,
                          qpos_sim ? qpos_sim + E * NQ : nullptr, qvel_sim ? qvel_sim + E * NV : nullptr);
   }
   if (frames && lane < 24) frames[E * 24 + lane] = L.oMf[lane / 12][lane % 12];
@@ -172,7 +173,7 @@ __global__ __launch_bounds__(WAVE) void k_reset(const DevModel<T> *__restrict__ 
 // walking reference update: one lane per env (Walk_Planner.py:23-31 samples -> WalkController.py:189-253)
 template <typename T>
 __global__ __launch_bounds__(256) void k_walk(int n, const T *coef, const int *side, const int *nsteps, const T *rest, const T *com,
-                                              int K, T t, T Tstep, T t_start, T omega, T z0, T dz, const T *frames, T *foot_ref,
+                                              int K, T t_now, const T *t_off, T Tstep, T t_start, T omega, T z0, T dz, const T *frames, T *foot_ref,
                                               T *contact_ref, uint8_t *cact, T *com_ref) {
   // 16 lanes per env: every lane evaluates the (cheap) polynomials, each writes its share of the rows, so
   // the table reads hit one line per env and the reference rows are written as contiguous runs
@@ -180,6 +181,9 @@ __global__ __launch_bounds__(256) void k_walk(int n, const T *coef, const int *s
   const int e = gid >> 4, r = gid & 15;
   if (e >= n) return;
   const size_t E = (size_t)e;
+  // per-env start delay (de-phased schedules): the env's own clock starts at t_off[e]
+  T t = t_now;
+  if (t_off) { t -= t_off[e]; t = t > 0 ? t : T(0); }
   // timeline: [0, t_start) both feet down; step k in [t_start + k T, t_start + (k+1) T); then the final stand
   const int k = t < t_start ? -1 : (int)floor((t - t_start) / Tstep);
   const T s = k < 0 ? t : (t - t_start) - k * Tstep;
@@ -266,6 +270,20 @@ struct Sect {
 
 struct Blob {
   std::vector<uint8_t> raw;
+  // every section must lie inside the blob (a truncated or corrupt file must not make the host read past it)
+  void validate() const {
+    const size_t nb = raw.size();
+    if (nb < 16) throw std::string("model blob: truncated header");
+    uint32_t n;
+    memcpy(&n, raw.data() + 8, 4);
+    if (n > 4096 || 16 + (size_t)n * sizeof(Sect) > nb) throw std::string("model blob: bad section table");
+    const Sect *s = (const Sect *)(raw.data() + 16);
+    for (uint32_t i = 0; i < n; i++) {
+      const size_t esz = s[i].dtype == 0 ? 8 : 4;
+      if (s[i].dtype > 1 || (s[i].offset & 7) || s[i].offset > nb || (size_t)s[i].count * esz > nb - s[i].offset)
+        throw std::string("model blob: bad section ") + std::string(s[i].name, strnlen(s[i].name, 24));
+    }
+  }
   const Sect *find(const char *name) const {
     uint32_t n;
     memcpy(&n, raw.data() + 8, 4);
@@ -545,14 +563,15 @@ static void need_refs(tsidb_ctx *h) {
 }
 
 template <typename T>
-static void launch_tick(tsidb_ctx *h, void *q, void *v, void *tau, void *dv, void *f, int32_t *status, void *obs,
+static void launch_tick(tsidb_ctx *h, void *q, void *v, void *tau, void *dv, void *f, int32_t *status, void *obs, int obs_ld,
                         void *frames, int32_t *info, hipStream_t s, const void *qpos_sim = nullptr,
                         const void *qvel_sim = nullptr) {
+  if (obs && obs_ld < NOBS) throw std::string("obs row stride must be at least TSIDB_NOBS");
 #define TSIDB_LAUNCH_TICK(NS)                                                                                              \
   hipLaunchKernelGGL((k_tick<T>), dim3(h->num_envs), dim3(WAVE), 0, s, (const DevModel<T> *)h->d_model, h->num_envs,   \
                      (T *)q, (T *)v, (const T *)h->com_ref, (const T *)h->posture_ref, (const T *)h->foot_ref,             \
                      (const T *)h->contact_ref, h->contact_active, (const T *)h->cop_frames, (T *)tau, (T *)dv, (T *)f,    \
-                     status, (T *)obs, (T *)frames, info, (const T *)qpos_sim, (const T *)qvel_sim)
+                     status, (T *)obs, obs_ld, (T *)frames, info, (const T *)qpos_sim, (const T *)qvel_sim)
   TSIDB_LAUNCH_TICK(2);
 #undef TSIDB_LAUNCH_TICK
   HIP_OK(hipGetLastError());
@@ -580,6 +599,7 @@ int tsidb_create(const void *model_blob, size_t nbytes, const double *params, in
     if (dtype != TSIDB_F64 && dtype != TSIDB_F32) throw std::string("dtype must be TSIDB_F64 or TSIDB_F32");
     h->device = device; h->dtype = dtype; h->num_envs = num_envs;
     h->blob.raw.assign((const uint8_t *)model_blob, (const uint8_t *)model_blob + nbytes);
+    h->blob.validate();
     h->params.assign(params, params + n_params);
     int ndev = 0;
     HIP_OK(hipGetDeviceCount(&ndev));
@@ -648,13 +668,13 @@ int tsidb_reset(tsidb_handle h, const int32_t *env_ids, int n_ids, void *q, void
   GUARD_END
 }
 
-int tsidb_tick(tsidb_handle h, void *q, void *v, void *tau, void *dv, void *f, int32_t *status, void *obs, void *frames,
-               int32_t *info, void *stream) {
+int tsidb_tick(tsidb_handle h, void *q, void *v, void *tau, void *dv, void *f, int32_t *status, void *obs, int obs_ld,
+               void *frames, int32_t *info, void *stream) {
   GUARD_BEGIN
   need_refs(h);
   if (!q || !v || !tau || !dv || !f || !status) throw std::string("tsidb_tick: null buffer");
-  if (h->dtype == TSIDB_F64) launch_tick<double>(h, q, v, tau, dv, f, status, obs, frames, info, (hipStream_t)stream);
-  else launch_tick<float>(h, q, v, tau, dv, f, status, obs, frames, info, (hipStream_t)stream);
+  if (h->dtype == TSIDB_F64) launch_tick<double>(h, q, v, tau, dv, f, status, obs, obs_ld, frames, info, (hipStream_t)stream);
+  else launch_tick<float>(h, q, v, tau, dv, f, status, obs, obs_ld, frames, info, (hipStream_t)stream);
   GUARD_END
 }
 
@@ -668,8 +688,8 @@ int tsidb_sim(tsidb_handle h, const void *q_tsid, const void *v_tsid, void *qpos
 }
 
 int tsidb_step(tsidb_handle h, void *q, void *v, void *qpos, void *qvel, void *qacc_ws, void *tau, void *dv, void *f,
-               int32_t *status, void *obs, void *frames, int32_t *ncon, int32_t *con_pairs, int32_t *info, int n_substeps,
-               void *stream) {
+               int32_t *status, void *obs, int obs_ld, void *frames, int32_t *ncon, int32_t *con_pairs, int32_t *info,
+               int n_substeps, void *stream) {
   GUARD_BEGIN
   need_refs(h);
   if (!q || !v || !tau || !dv || !f || !status) throw std::string("tsidb_step: null buffer");
@@ -679,10 +699,10 @@ int tsidb_step(tsidb_handle h, void *q, void *v, void *qpos, void *qvel, void *q
   for (int it = 0; it < n_substeps; it++) {
     // closed loop: the tick reads the sim state, the sim is driven by tau and keeps its own base pose
     if (h->dtype == TSIDB_F64) {
-      launch_tick<double>(h, q, v, tau, dv, f, status, obs, frames, info, s, closed ? qpos : nullptr, closed ? qvel : nullptr);
+      launch_tick<double>(h, q, v, tau, dv, f, status, obs, obs_ld, frames, info, s, closed ? qpos : nullptr, closed ? qvel : nullptr);
       if (sim) launch_sim<double>(h, closed ? nullptr : q, closed ? nullptr : v, qpos, qvel, qacc_ws, nullptr, ncon, con_pairs, info, s, closed ? tau : nullptr);
     } else {
-      launch_tick<float>(h, q, v, tau, dv, f, status, obs, frames, info, s, closed ? qpos : nullptr, closed ? qvel : nullptr);
+      launch_tick<float>(h, q, v, tau, dv, f, status, obs, obs_ld, frames, info, s, closed ? qpos : nullptr, closed ? qvel : nullptr);
       if (sim) launch_sim<float>(h, closed ? nullptr : q, closed ? nullptr : v, qpos, qvel, qacc_ws, nullptr, ncon, con_pairs, info, s, closed ? tau : nullptr);
     }
   }
@@ -691,7 +711,7 @@ int tsidb_step(tsidb_handle h, void *q, void *v, void *qpos, void *qvel, void *q
 
 int tsidb_walk_update(tsidb_handle h, const void *coef, const int32_t *side, const int32_t *nsteps, const void *rest,
                       const void *com, int K, double t, double step_duration, double t_start, double omega, double com_z0,
-                      double com_drop, const void *frames, void *stream) {
+                      double com_drop, const void *frames, const void *t_offset, void *stream) {
   GUARD_BEGIN
   need_refs(h);
   if (!coef || !side || !nsteps || !rest || !com || !frames || K <= 0) throw std::string("tsidb_walk_update: null table or K <= 0");
@@ -700,12 +720,12 @@ int tsidb_walk_update(tsidb_handle h, const void *coef, const int32_t *side, con
   const int grid = (h->num_envs * 16 + 255) / 256;
   if (h->dtype == TSIDB_F64)
     hipLaunchKernelGGL(k_walk<double>, dim3(grid), dim3(256), 0, s, h->num_envs, (const double *)coef, side, nsteps,
-                       (const double *)rest, (const double *)com, K, t, step_duration, t_start, omega, com_z0, com_drop,
+                       (const double *)rest, (const double *)com, K, t, (const double *)t_offset, step_duration, t_start, omega, com_z0, com_drop,
                        (const double *)frames, (double *)h->foot_ref, (double *)h->contact_ref, (uint8_t *)h->contact_active,
                        (double *)h->com_ref);
   else
     hipLaunchKernelGGL(k_walk<float>, dim3(grid), dim3(256), 0, s, h->num_envs, (const float *)coef, side, nsteps,
-                       (const float *)rest, (const float *)com, K, (float)t, (float)step_duration, (float)t_start, (float)omega,
+                       (const float *)rest, (const float *)com, K, (float)t, (const float *)t_offset, (float)step_duration, (float)t_start, (float)omega,
                        (float)com_z0, (float)com_drop, (const float *)frames, (float *)h->foot_ref, (float *)h->contact_ref,
                        (uint8_t *)h->contact_active, (float *)h->com_ref);
   HIP_OK(hipGetLastError());

@@ -31,6 +31,7 @@ constexpr int LDJ = 51;  // padded leading dimension of the 50x50 J factor in LD
 constexpr int LDD = 51;  // leading dimension of the dynamics rows [M | -Jc^T]
 constexpr int LDF = 27;  // leading dimension of frame / CoM Jacobians
 constexpr int NOBS = 65;
+constexpr int NROW = 67; // obs row + reward + done when the caller's row stride has room for them
 constexpr int MAXCON = 32;
 constexpr int MAXCHILD = 6;
 constexpr int WAVE = 64;
@@ -40,7 +41,8 @@ enum {
   P_DT = 0, P_MU, P_FMIN, P_FMAX, P_W_FORCEREF, P_KP_CONTACT, P_KD_CONTACT, P_W_FOOT, P_KP_FOOT, P_KD_FOOT,
   P_W_COM, P_KP_COM, P_KD_COM, P_W_POSTURE, P_HESS_REG, P_QUIRKS, P_NORMAL, P_CPOINTS = P_NORMAL + 3,
   P_KP_POSTURE = P_CPOINTS + 12, P_KD_POSTURE = P_KP_POSTURE + 20, P_TAU_MAX = P_KD_POSTURE + 20,
-  P_V_MAX = P_TAU_MAX + 20, P_MAX_ITER = P_V_MAX + 20, P_SIM_ENABLED, P_CLOSED_LOOP, P_W_AM, P_KP_AM /*3*/, P_COUNT = 128
+  P_V_MAX = P_TAU_MAX + 20, P_MAX_ITER = P_V_MAX + 20, P_SIM_ENABLED, P_CLOSED_LOOP, P_W_AM, P_KP_AM /*3*/,
+  P_REW_SIGMA = P_KP_AM + 3, P_REW_CTAU, P_DONE_HEIGHT, P_DONE_TILT, P_SELF_COLLISION, P_W_COP, P_COUNT = 128
 };
 
 // Model constants in the arithmetic type of the path; one copy in HBM, read by every workgroup

@@ -896,7 +896,7 @@ template <typename T, int NS>
 __device__ __forceinline__ void tsid_tick_env(const DevModel<T> &m, TickLds<T> &L, int lane, T *q, T *v, const T *com_ref,
                               const T *posture_ref, const T *foot_ref, const T *contact_ref,
                               const uint8_t *cact, const T *cop_frames, T *tau, T *dv, T *fout, int *status_out,
-                              T *obs, int *info, const T *qpos_sim, const T *qvel_sim) {
+                              T *obs, T *rowx, int *info, const T *qpos_sim, const T *qvel_sim) {
   TSIDB_STAMP(0);
   // ---- stage state.  Closed loop: the TSID state is read from the sim state each
   //      tick - quat wxyz -> xyzw, world-frame base linear velocity -> body frame, sim joint order ->
@@ -1043,11 +1043,14 @@ __device__ __forceinline__ void tsid_tick_env(const DevModel<T> &m, TickLds<T> &
     fout[lane] = val;
     L.as.s[lane] = val; // staged for the CoP
   }
+  T tau2 = 0;
   if (lane < NA) {
     T t = L.h[6 + lane];
     for (int e = 0; e < n; e++) t += L.Dyn[(6 + lane) * LDD + e] * L.x[e];
     tau[lane] = t;
+    tau2 = t * t;
   }
+  if (rowx) tau2 = wave_sum(tau2);
   if (lane == 0) {
     status_out[0] = status;
     if (info) { info[0] = iters; info[1] = c.iq; }
@@ -1135,6 +1138,21 @@ __device__ __forceinline__ void tsid_tick_env(const DevModel<T> &m, TickLds<T> &
   if (obs) {
     if (lane < NQ) obs[lane] = L.qs[lane];
     if (lane < NV) obs[NQ + lane] = L.vs[lane];
+  }
+  // ---- reward / done (SURVEY.md 8d write list; no reference counterpart): tracking reward on this tick's CoM
+  //      error minus a torque penalty; done = failed QP or fallen (base height / tilt of the new state)
+  if (rowx && lane == 0) {
+    T rew = 0, dn = 1;
+    if (status == 0) {
+      const T up = 1 - 2 * (L.qs[3] * L.qs[3] + L.qs[4] * L.qs[4]);
+      const bool fall = L.qs[2] < m.params[P_DONE_HEIGHT] || up < m.params[P_DONE_TILT];
+      const T e0 = L.com[0] - com_ref[0], e1 = L.com[1] - com_ref[1], e2 = L.com[2] - com_ref[2];
+      const T sg = m.params[P_REW_SIGMA];
+      dn = fall ? T(1) : T(0);
+      rew = fall ? T(0) : exp(-(e0 * e0 + e1 * e1 + e2 * e2) / (sg * sg)) - m.params[P_REW_CTAU] * tau2;
+    }
+    rowx[0] = rew;
+    rowx[1] = dn;
   }
   TSIDB_STAMP(9);
 }

@@ -32,6 +32,12 @@ P_SIM_ENABLED = 112
 P_CLOSED_LOOP = 113
 P_W_AM = 114
 P_KP_AM = 115
+P_REW_SIGMA = 118
+P_REW_CTAU = 119
+P_DONE_HEIGHT = 120
+P_DONE_TILT = 121
+P_SELF_COLLISION = 122
+P_W_COP = 123
 P_COUNT = 128
 
 
@@ -72,6 +78,13 @@ def pack_params(conf, effort_limit, velocity_limit):
     # angular-momentum task of the legacy controller (legacy/biped.py:82-87); off in ctrl/WalkController.py
     p[P_W_AM] = getattr(conf, "w_am", 0.0)
     p[P_KP_AM:P_KP_AM + 3] = getattr(conf, "kp_am", 10.0) * np.asarray(getattr(conf, "mask_am", (1.0, 1.0, 0.0)))
+    # reward / done outputs (no reference counterpart; SURVEY.md 8d write list)
+    p[P_REW_SIGMA] = getattr(conf, "reward_com_sigma", 0.05)
+    p[P_REW_CTAU] = getattr(conf, "reward_torque_cost", 1e-3)
+    p[P_DONE_HEIGHT] = getattr(conf, "done_base_height", 0.2)
+    p[P_DONE_TILT] = np.cos(np.deg2rad(getattr(conf, "done_tilt_deg", 45.0)))
+    p[P_SELF_COLLISION] = 1.0 if getattr(conf, "self_collision", False) else 0.0
+    p[P_W_COP] = getattr(conf, "w_cop", 0.0)
     if p[P_CLOSED_LOOP] and not p[P_SIM_ENABLED]:
         raise ValueError("closed_loop needs the sim stage (sim_enabled=True)")
     return p

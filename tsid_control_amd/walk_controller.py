@@ -21,7 +21,7 @@ from .conf import RobotConfig
 from .model import ModelBlob
 from .params import P_COUNT, pack_params
 
-NQ, NV, NA, NOBS, MAXCON = 27, 26, 20, 65, 32
+NQ, NV, NA, NOBS, NROW, MAXCON = 27, 26, 20, 65, 67, 32
 
 
 def _ptr(t):
@@ -69,7 +69,11 @@ class WalkController:
         # outputs
         self.tau, self.dv, self.f = z(N, NA), z(N, NV), z(N, 24)
         self.status = z(N, dt=torch.int32)
-        self.obs, self.frames = z(N, NOBS), z(N, 2, 12)
+        # one contiguous row per env = obs[65] + reward + done: what the all-gather sends
+        self.rows = z(N, NROW)
+        self.obs, self.reward, self.done = self.rows[:, :NOBS], self.rows[:, NOBS], self.rows[:, NOBS + 1]
+        self.gather_width = NROW
+        self.frames = z(N, 2, 12)
         self.ncon, self.con_pairs = z(N, dt=torch.int32), z(N, MAXCON, dt=torch.int32)
         self.info = z(N, 4, dt=torch.int32)
         self.env_params = None
@@ -117,6 +121,7 @@ class WalkController:
         """Per-env randomisation of the sim stage (BASELINE config 5; no reference counterpart): any
         of mass_scale [N], friction [N], floor_normal [N,3] (normalised here), floor_offset [N].
         Calling with no argument restores the nominal model."""
+        self.sync_sim()  # a sim stage left in flight by step_pipelined() may still read the old table
         if mass_scale is None and friction is None and floor_normal is None and floor_offset is None:
             self.env_params = None
             rc = self._L.tsidb_set_env_params(self._h, None)
@@ -152,6 +157,7 @@ class WalkController:
     def reset(self, env_ids=None):
         """Standing state with the soles on z = 0 and all references re-captured
         (WalkController.py:22-26,72-79,81,122,151-152,164-165; main.py:57-64)."""
+        self.sync_sim()  # step_pipelined() may have left a sim stage running on the side stream
         ids = None
         n_ids = 0
         if env_ids is not None:
@@ -173,10 +179,11 @@ class WalkController:
         """One env step for every env: TSID tick (main.py:119-129) then, if conf.sim_enabled, base
         teleport + joint targets + sim step (main.py:192-195).  Returns (tau, q, v, status, obs);
         all are views of the controller's tensors, updated in place."""
+        self.sync_sim()
         with torch.cuda.device(self.device):
             rc = self._L.tsidb_step(self._h, _ptr(self.q), _ptr(self.v), _ptr(self.qpos), _ptr(self.qvel),
                                     _ptr(self.qacc_warmstart), _ptr(self.tau), _ptr(self.dv), _ptr(self.f),
-                                    _ptr(self.status), _ptr(self.obs), _ptr(self.frames), _ptr(self.ncon),
+                                    _ptr(self.status), _ptr(self.rows), NROW, _ptr(self.frames), _ptr(self.ncon),
                                     _ptr(self.con_pairs), _ptr(self.info), int(n_substeps), self._stream())
         _lib.check(self._L, self._h, rc, "tsidb_step")
         self.t += n_substeps * self.conf.dt
@@ -216,13 +223,20 @@ class WalkController:
             P["stream"].wait_event(ready)
             if events:
                 events[2].record(P["stream"])
-            self.sim_step(q_tsid=P["q"][par], v_tsid=P["v"][par])
+            self.sim_step(q_tsid=P["q"][par], v_tsid=P["v"][par], _from_pipe=True)
             if events:
                 events[3].record(P["stream"])
             P["done"][par] = torch.cuda.Event()
             P["done"][par].record(P["stream"])
         self.t += self.conf.dt
         return self.tau, self.q, self.v, self.status, self.obs
+
+    def gather_rows(self, out=None):
+        """[N, 67] = obs, reward, done of the last tick: the per-env row the multi-GPU all-gather carries."""
+        if out is None:
+            return self.rows
+        out.copy_(self.rows)
+        return out
 
     def sync_sim(self):
         """Make the current stream wait for the sim stages step_pipelined() left in flight."""
@@ -234,15 +248,17 @@ class WalkController:
         """TSID stage only (main.py:119-129)."""
         with torch.cuda.device(self.device):
             rc = self._L.tsidb_tick(self._h, _ptr(self.q), _ptr(self.v), _ptr(self.tau), _ptr(self.dv), _ptr(self.f),
-                                    _ptr(self.status), _ptr(self.obs), _ptr(self.frames), _ptr(self.info), self._stream())
+                                    _ptr(self.status), _ptr(self.rows), NROW, _ptr(self.frames), _ptr(self.info), self._stream())
         _lib.check(self._L, self._h, rc, "tsidb_tick")
         return self.tau, self.q, self.v, self.status, self.obs
 
-    def sim_step(self, teleport=True, q_tsid=None, v_tsid=None):
+    def sim_step(self, teleport=True, q_tsid=None, v_tsid=None, _from_pipe=False):
         """Sim stage only (main.py:192-195); teleport=False steps the sim state on its own; q_tsid / v_tsid
         override the TSID state the base pose / joint targets (and, with reference_quirks=False, the base
         velocity) are taken from (snapshots of self.q / self.v when the sim stage runs on another stream
         than the tick)."""
+        if not _from_pipe:
+            self.sync_sim()
         src = q_tsid if q_tsid is not None else self.q
         srcv = v_tsid if v_tsid is not None else self.v
         with torch.cuda.device(self.device):

@@ -149,6 +149,12 @@ class WalkSchedule:
         self.side, self.nsteps = t(side, torch.long), t(nsteps, torch.long)
         self.N, self.K = N, K
         self.device, self.dtype = device, dtype
+        self.t_offset = None  # [N] per-env start delay (set_phase_offsets); None = every env on the same clock
+
+    def set_phase_offsets(self, t_offset):
+        """De-phase the batch: env e follows its timeline on the clock max(t - t_offset[e], 0), so that single-
+        and double-support ticks (38- / 50-variable QPs) mix inside one launch.  Device path (apply) only."""
+        self.t_offset = None if t_offset is None else torch.as_tensor(t_offset, device=self.device).to(self.dtype).contiguous()
 
     @classmethod
     def from_demo_paths(cls, num_envs, conf: RobotConfig, device, dtype, seed=1, q0_feet=None, com0=None, **kw):
@@ -259,5 +265,6 @@ class WalkSchedule:
             rc = wc._L.tsidb_walk_update(wc._h, p(self._coef_c), p(self._side32), p(self._nsteps32), p(self._rest_c),
                                          p(self._com_c), self.K, float(t), float(self.conf.step_duration),
                                          float(self.t_start), float(self.omega), float(self.z0), float(self.dz),
-                                         p(wc.frames), wc._stream())
+                                         p(wc.frames), p(self.t_offset) if self.t_offset is not None else None,
+                                         wc._stream())
         _lib.check(wc._L, wc._h, rc, "tsidb_walk_update")
