@@ -66,8 +66,11 @@ int tsidb_set_refs(tsidb_handle h, const void *com_ref, const void *posture_ref,
 /* per-env randomisation of the sim stage (BASELINE.json configs[4]; no reference counterpart):
  * env_params [N,8] in the path's arithmetic type = mass scale applied to every sim body's mass and inertia,
  * contact friction, unit floor normal (3), floor offset d (plane n.x = d), 2 spare.  NULL = nominal
- * model (floor z = 0, friction 1).  The pointer is remembered, not copied. */
-int tsidb_set_env_params(tsidb_handle h, const void *env_params);
+ * model (floor z = 0, friction 1).  terrain [N,20] (may be NULL = flat) = stepped floor: direction (2, unit, world xy),
+ * phase, 1 / step length, heights[16] - the floor surface is raised along its normal by heights[cell & 15] with
+ * cell = floor((direction . x_world_xy - phase) / step length) ("rough-terrain contacts", 1 cm steps).  The pointers
+ * are remembered, not copied. */
+int tsidb_set_env_params(tsidb_handle h, const void *env_params, const void *terrain);
 
 /* reset: WalkController.py:22-26,72-79 (standing state, soles onto z = 0), the references of
  * :81,122,151-152,164-165, and main.py:57-64 (mj_data.qpos = q).  env_ids (device, int32) selects

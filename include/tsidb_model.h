@@ -43,6 +43,9 @@
  *                                   local to the body's hull (edges of the triangulated hull)
  *   mj_chunk_adr      i32 [22]      first chunk of each body; mj_chunk_box f64 [188][6] centre, half extent
  *   mj_rbound         f64 [21][4]   bounding sphere (centre in the body frame, radius)
+ *   mj_hull_center    f64 [21][3]   centre of mass of the solid hull, body frame (the geom centre MuJoCo's convex
+ *                                   collision starts its portal search from)
+ *   mj_hull_box       f64 [21][6]   body-frame bounding box of the hull: centre, half extents (mid phase)
  *   mj_pairs          i32 [170][2]  robot<->robot candidate body pairs (after excludes and parent-child filter)
  *   mj_opt            f64 [7]       timestep, gravity z, tolerance, iterations, ls_iterations, ls_tolerance, impratio
  *   mj_contact        f64 [8]       friction mu, solref (2), solimp (5)  - MuJoCo defaults (no geom contact attrs)

@@ -36,7 +36,7 @@ int or_env_step_batch_env(const OrModel *m, const double *params, int n, double 
                           int32_t *status, double *obs, int32_t *ncon, int32_t *con_geom, int nthreads) {
   return or_env_step_batch_walk(m, params, n, q, v, qpos, qvel, qacc_ws, (double *)com_ref, posture_ref, (double *)foot_ref,
                                 (double *)contact_ref, (uint8_t *)contact_active, cop_frames, env_params, tau, dv, f, status, obs,
-                                ncon, con_geom, nthreads, NULL, NULL, NULL);
+                                ncon, con_geom, nthreads, NULL, NULL, NULL, NULL);
 }
 
 /* the same env step preceded, per env, by the walking reference update of or_walk.c when `w` is given (the
@@ -47,7 +47,7 @@ int or_env_step_batch_walk(const OrModel *m, const double *params, int n, double
                            double *foot_ref, double *contact_ref, uint8_t *contact_active,
                            const double *cop_frames, const double *env_params, double *tau, double *dv, double *f,
                            int32_t *status, double *obs, int32_t *ncon, int32_t *con_geom, int nthreads,
-                           const OrWalkTables *w, double *frames, double *rewdone) {
+                           const OrWalkTables *w, double *frames, double *rewdone, const double *terrain) {
   const int sim = params[P_SIM_ENABLED] != 0.0;
   const int closed = params[P_CLOSED_LOOP] != 0.0;
   const int quirks = params[P_QUIRKS] != 0.0 && !closed;
@@ -93,8 +93,9 @@ int or_env_step_batch_walk(const OrModel *m, const double *params, int n, double
       for (int a = 0; a < OR_NA; a++) ctrl[a] = qe[m->mj_ctrl_qidx[a]];
     }
     OrSimInfo info;
-    int rc = or_sim_step_full(m, qp, qv, ctrl, closed ? tau + (size_t)e * OR_NA : NULL, qacc_ws + (size_t)e * OR_NV,
-                              env_params ? env_params + (size_t)e * 8 : NULL, &info);
+    int rc = or_sim_step_ext(m, qp, qv, ctrl, closed ? tau + (size_t)e * OR_NA : NULL, qacc_ws + (size_t)e * OR_NV,
+                             env_params ? env_params + (size_t)e * 8 : NULL, terrain ? terrain + (size_t)e * 20 : NULL,
+                             params[P_SELF_COLLISION] != 0.0, &info);
     if (rc) status[e] |= 0x100;
     if (ncon) ncon[e] = info.ncon;
     if (con_geom) {

@@ -70,6 +70,13 @@ OrModel *or_model_load(const void *blob, size_t nbytes) {
   e |= geti(b, "mj_ctrl_qidx", m->mj_ctrl_qidx, OR_NA);
   e |= geti(b, "mj_hull_adr", m->hull_adr, OR_NB + 1);
   e |= getf(b, "mj_rbound", &m->rbound[0][0], OR_NB * 4);
+  e |= getf(b, "mj_hull_center", &m->hull_center[0][0], OR_NB * 3);
+  e |= getf(b, "mj_hull_box", &m->hull_box[0][0], OR_NB * 6);
+  {
+    const Sect *ps = find(b, "mj_pairs");
+    if (!ps || ps->dtype != 1 || ps->count > 2 * OR_MAXPAIR) e |= -1;
+    else { m->npair = (int)(ps->count / 2); memcpy(m->pairs, b + ps->offset, ps->count * sizeof(int)); }
+  }
   e |= getf(b, "mj_opt", m->opt, 7);
   e |= getf(b, "mj_contact", m->contact, 8);
   const Sect *hv = find(b, "mj_hull_vert"), *ea = find(b, "mj_hull_eadr"), *ed = find(b, "mj_hull_edge");

@@ -13,7 +13,9 @@
  *    1e-9 m of the minimum tie-break to the lowest index (MuJoCo hill-climbs the hull graph).
  *  - line search: safeguarded Newton on the exact 1-D piecewise-quadratic cost to MuJoCo's
  *    gradient tolerance (MuJoCo's bracketing schedule differs; both stop at |dcost| < gtol).
- *  - robot<->robot hull pairs are not collided (round 1).
+ *  - robot<->robot hull pairs: or_collide.c (MPR run to 1e-10 instead of MuJoCo's 1e-6 tolerance).
+ *  - at most OR_MAXCON contacts per env, of which at most OR_MAXHH robot<->robot ones (flag bit 8 when a
+ *    penetrating pair had to be dropped).
  */
 #include "oracle.h"
 #include <math.h>
@@ -164,6 +166,22 @@ int or_sim_step_env(const OrModel *m, double *qpos, double *qvel, const double *
  * instead of the position servos */
 int or_sim_step_full(const OrModel *m, double *qpos, double *qvel, const double *ctrl, const double *motor_tau,
                      double *qacc_ws, const double *envp, OrSimInfo *info) {
+  return or_sim_step_ext(m, qpos, qvel, ctrl, motor_tau, qacc_ws, envp, NULL, 0, info);
+}
+
+/* mju_makeFrame: tangents of a contact frame from its normal (t1 from y unless |n_y| >= 0.5, t2 = n x t1) */
+static void make_frame(const double *nrm, double *t1, double *t2) {
+  double t[3] = {0, 0, 0};
+  if (fabs(nrm[1]) < 0.5) t[1] = 1; else t[2] = 1;
+  double dn = dot3(nrm, t), nn = 0;
+  for (int i = 0; i < 3; i++) { t1[i] = t[i] - dn * nrm[i]; nn += t1[i] * t1[i]; }
+  nn = 1.0 / sqrt(nn);
+  for (int i = 0; i < 3; i++) t1[i] *= nn;
+  cross(nrm, t1, t2);
+}
+
+int or_sim_step_ext(const OrModel *m, double *qpos, double *qvel, const double *ctrl, const double *motor_tau,
+                    double *qacc_ws, const double *envp, const double *terr, int self_collision, OrSimInfo *info) {
   const double dt = m->opt[0], gz = m->opt[1], tol = m->opt[2];
   const int maxiter = (int)m->opt[3], ls_iter = (int)m->opt[4];
   const double ls_tol = m->opt[5];
@@ -295,24 +313,19 @@ int or_sim_step_full(const OrModel *m, double *qpos, double *qvel, const double 
 
   /* ---------------- collision: floor plane (z = 0, normal +z) vs every body's hull */
   /* floor plane n.x = d and its contact frame (mju_makeFrame: t1 from y unless |n_y| >= 0.5, t2 = n x t1) */
-  double nrm[3] = {0, 0, 1}, t1[3], t2[3], pd = 0.0;
+  double nrm[3] = {0, 0, 1}, pd = 0.0;
   if (envp) { nrm[0] = envp[2]; nrm[1] = envp[3]; nrm[2] = envp[4]; pd = envp[5]; }
-  {
-    double t[3] = {0, 0, 0};
-    if (fabs(nrm[1]) < 0.5) t[1] = 1; else t[2] = 1;
-    double dn = dot3(nrm, t), nn = 0;
-    for (int i = 0; i < 3; i++) { t1[i] = t[i] - dn * nrm[i]; nn += t1[i] * t1[i]; }
-    nn = 1.0 / sqrt(nn);
-    for (int i = 0; i < 3; i++) t1[i] *= nn;
-    cross(nrm, t1, t2);
-  }
+  /* stepped terrain (BASELINE configs[4]; or_collide.c): the floor surface is raised along the normal by the
+   * height of the cell under each point */
+  double hmax = 0.0;
+  if (terr) for (int i = 0; i < 16; i++) hmax = fmax(hmax, terr[4 + i]);
   const double margin = 0.0;
   int ncon = 0;
   for (int b = 0; b < NB && ncon < OR_MAXCON; b++) {
     double cw[3];
     matvec(Rb[b], m->rbound[b], cw);
     for (int i = 0; i < 3; i++) cw[i] += pb[b][i];
-    if (dot3(nrm, cw) - pd - m->rbound[b][3] > margin) continue;
+    if (dot3(nrm, cw) - pd - m->rbound[b][3] - hmax > margin) continue;
     /* floor normal in the body frame, plane offset seen from the body origin */
     const double rn[3] = {nrm[0] * Rb[b][0] + nrm[1] * Rb[b][3] + nrm[2] * Rb[b][6],
                           nrm[0] * Rb[b][1] + nrm[1] * Rb[b][4] + nrm[2] * Rb[b][7],
@@ -320,15 +333,25 @@ int or_sim_step_full(const OrModel *m, double *qpos, double *qvel, const double 
     const double pz = dot3(nrm, pb[b]) - pd;
     int v0 = m->hull_adr[b], v1 = m->hull_adr[b + 1];
     double zmin = INFINITY;
+#define VERT_DIST(i, z)                                                                     \
+  do {                                                                                      \
+    const double *v_ = m->hull_vert + 3 * (i);                                              \
+    (z) = rn[0] * v_[0] + rn[1] * v_[1] + rn[2] * v_[2] + pz;                                \
+    if (terr) {                                                                             \
+      double w_[3];                                                                         \
+      matvec(Rb[b], v_, w_);                                                                \
+      (z) -= or_terrain_height(terr, w_[0] + pb[b][0], w_[1] + pb[b][1]);                    \
+    }                                                                                       \
+  } while (0)
     for (int i = v0; i < v1; i++) {
-      const double *v = m->hull_vert + 3 * i;
-      double z = rn[0] * v[0] + rn[1] * v[1] + rn[2] * v[2] + pz;
+      double z;
+      VERT_DIST(i, z);
       if (z < zmin) zmin = z;
     }
     int best = -1;
     for (int i = v0; i < v1 && best < 0; i++) {
-      const double *v = m->hull_vert + 3 * i;
-      double z = rn[0] * v[0] + rn[1] * v[1] + rn[2] * v[2] + pz;
+      double z;
+      VERT_DIST(i, z);
       if (z <= zmin + TIE_TOL) best = i;
     }
     if (zmin > margin) continue;
@@ -341,21 +364,39 @@ int or_sim_step_full(const OrModel *m, double *qpos, double *qvel, const double 
       double w[3];
       matvec(Rb[b], v, w);
       for (int i = 0; i < 3; i++) w[i] += pb[b][i];
-      double dist = dot3(nrm, w) - pd;
+      double dist = dot3(nrm, w) - pd - or_terrain_height(terr, w[0], w[1]);
       if (c > 0 && dist > margin) continue;
       info->con_geom[ncon] = b;
       info->con_vert[ncon] = cand[c] - v0;
+      info->con_body1[ncon] = -1;
+      memcpy(info->con_frame[ncon], nrm, sizeof nrm);
       info->con_dist[ncon] = dist;
       for (int i = 0; i < 3; i++) info->con_pos[ncon][i] = w[i] - 0.5 * dist * nrm[i];
       ncon++;
     }
+  }
+#undef VERT_DIST
+  /* ---------------- collision: robot<->robot convex-hull pairs (robot.xml:13-15,18-52; or_collide.c) */
+  if (self_collision) {
+    int b1[OR_MAXHH], b2[OR_MAXHH], over = 0;
+    double hd[OR_MAXHH], hp[OR_MAXHH][3], hn[OR_MAXHH][3];
+    const int nh = or_collide_pairs(m, Rb, pb, ncon, b1, b2, hd, hp, hn, &over);
+    for (int k = 0; k < nh; k++, ncon++) {
+      info->con_geom[ncon] = b2[k];
+      info->con_vert[ncon] = 0x8000 | b1[k];
+      info->con_body1[ncon] = b1[k];
+      memcpy(info->con_frame[ncon], hn[k], 24);
+      info->con_dist[ncon] = hd[k];
+      memcpy(info->con_pos[ncon], hp[k], 24);
+    }
+    if (over) info->flags |= 8;
   }
   info->ncon = ncon;
 
   /* ---------------- constraint rows: frictionloss dofs, then pyramidal contact rows */
   static __thread Efc e;
   e.nefc = 0;
-  const double mu = envp ? envp[1] : m->contact[0];
+  const double mu_floor = envp ? envp[1] : m->contact[0];
   const double timeconst = m->contact[1] > 2 * dt ? m->contact[1] : 2 * dt, dampratio = m->contact[2];
   const double dmin = m->contact[3], dmax = m->contact[4], width = m->contact[5], mid = m->contact[6], power = m->contact[7];
   const double kk = 1.0 / (dmax * dmax * timeconst * timeconst * dampratio * dampratio), bb = 2.0 / (dmax * timeconst);
@@ -373,15 +414,23 @@ int or_sim_step_full(const OrModel *m, double *qpos, double *qvel, const double 
   }
   for (int c = 0; c < ncon; c++) {
     int b = info->con_geom[c];
-    const double *r = info->con_pos[c];
+    const int b1 = info->con_body1[c];
+    const double *r = info->con_pos[c], *nrm = info->con_frame[c];
+    const double mu = b1 >= 0 ? m->contact[0] : mu_floor; /* robot geoms keep the model's friction */
+    double t1[3], t2[3];
+    make_frame(nrm, t1, t2);
+    /* point Jacobian of geom2's body minus that of geom1's body (the floor does not move) */
     double Jp[3][NV];
     memset(Jp, 0, sizeof Jp);
-    for (int a = b; a >= 0; a = m->mj_parent[a]) {
-      int k0 = a == 0 ? 0 : 5 + a, k1 = a == 0 ? 5 : 5 + a;
-      for (int k = k0; k <= k1; k++) {
-        double wxr[3];
-        cross(S[k] + 3, r, wxr);
-        for (int i = 0; i < 3; i++) Jp[i][k] = S[k][i] + wxr[i];
+    for (int side = 0; side < 2; side++) {
+      const double sg = side == 0 ? 1.0 : -1.0;
+      for (int a = side == 0 ? b : b1; a >= 0; a = m->mj_parent[a]) {
+        int k0 = a == 0 ? 0 : 5 + a, k1 = a == 0 ? 5 : 5 + a;
+        for (int k = k0; k <= k1; k++) {
+          double wxr[3];
+          cross(S[k] + 3, r, wxr);
+          for (int i = 0; i < 3; i++) Jp[i][k] += sg * (S[k][i] + wxr[i]);
+        }
       }
     }
     double Jn[NV], Jt[2][NV];
@@ -401,7 +450,7 @@ int or_sim_step_full(const OrModel *m, double *qpos, double *qvel, const double 
       else y = 1 - pow(1 - x, power) / pow(1 - mid, power - 1);
       imp = dmin + y * (dmax - dmin);
     }
-    double tran = m->mj_body_invw0[b][0]; /* world body contributes 0 */
+    double tran = m->mj_body_invw0[b][0] + (b1 >= 0 ? m->mj_body_invw0[b1][0] : 0.0); /* world body contributes 0 */
     double diagA = tran + mu * mu * tran;
     double R0 = fmax(MINVAL, (1 - imp) / imp * diagA);
     double Rpy = 2 * mu * mu * R0;

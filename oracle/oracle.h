@@ -20,7 +20,7 @@ extern "C" {
 
 enum { OR_NJ = 21, OR_NQ = 27, OR_NV = 26, OR_NA = 20, OR_NB = 21, OR_NF = 2 };
 enum { OR_NVAR = 50, OR_NEQ = 18, OR_NIN = 160 };
-enum { OR_MAXCON = 32, OR_MAXEFC = 20 + 4 * OR_MAXCON, OR_NOBS = 65 };
+enum { OR_MAXCON = 32, OR_MAXHH = 12 /* robot<->robot contacts per env */, OR_MAXEFC = 20 + 4 * OR_MAXCON, OR_NOBS = 65, OR_MAXPAIR = 256 };
 
 /* parameter vector indices (RobotConfig values; ctrl/conf.py:21-72) */
 enum {
@@ -55,6 +55,9 @@ typedef struct {
   const int *hull_eadr;    /* [nhullvert+1] */
   const int *hull_edge;    /* neighbour ids local to the body's hull */
   double rbound[OR_NB][4];
+  double hull_center[OR_NB][3]; /* centre of mass of the solid hull, body frame */
+  double hull_box[OR_NB][6];    /* body-frame bounding box: centre, half extents */
+  int npair, pairs[2 * OR_MAXPAIR]; /* robot<->robot candidate body pairs (excludes + parent-child filtered) */
   double opt[7];     /* dt gz tol iters ls_iters ls_tol impratio */
   double contact[8]; /* mu solref[2] solimp[5] */
   double meaninertia;
@@ -112,11 +115,14 @@ int or_tsid_tick(const OrModel *m, const double *params, double *q, double *v, c
 /* MuJoCo-subset step for one env: main.py:195 */
 typedef struct {
   int ncon, nefc, solver_iter;
-  int con_geom[OR_MAXCON]; /* body index of the mesh geom (geom1 is always the floor plane) */
-  int con_vert[OR_MAXCON];
+  int con_geom[OR_MAXCON]; /* body of geom2 (the mesh); geom1 is the floor plane unless con_body1 >= 0 */
+  int con_vert[OR_MAXCON]; /* floor contacts: hull vertex; robot<->robot contacts: 0x8000 | body of geom1 */
   double con_dist[OR_MAXCON], con_pos[OR_MAXCON][3];
   double efc_force[OR_MAXEFC];
   double qacc[OR_NV], qacc_smooth[OR_NV], qfrc_bias[OR_NV], qfrc_actuator[OR_NV], M[OR_NV][OR_NV];
+  int con_body1[OR_MAXCON];      /* -1 = floor */
+  double con_frame[OR_MAXCON][3]; /* contact normal (geom1 -> geom2), world */
+  int flags;                      /* bit 3 (8): a penetrating robot<->robot pair was dropped (contact caps) */
 } OrSimInfo;
 int or_sim_step(const OrModel *m, double *qpos, double *qvel, const double *ctrl, double *qacc_ws,
                 OrSimInfo *info);
@@ -125,6 +131,15 @@ int or_sim_step_env(const OrModel *m, double *qpos, double *qvel, const double *
                     const double *envp, OrSimInfo *info);
 int or_sim_step_full(const OrModel *m, double *qpos, double *qvel, const double *ctrl, const double *motor_tau,
                      double *qacc_ws, const double *envp, OrSimInfo *info);
+/* full form: terr = stepped-terrain table (20 doubles, or_collide.c) or NULL; self_collision != 0 collides the
+ * robot<->robot hull pairs as mj_step does (robot.xml:13-15,18-52) */
+int or_sim_step_ext(const OrModel *m, double *qpos, double *qvel, const double *ctrl, const double *motor_tau,
+                    double *qacc_ws, const double *envp, const double *terr, int self_collision, OrSimInfo *info);
+double or_terrain_height(const double *terr, double X, double Y);
+int or_mpr_penetration(const OrModel *m, int a, const double *Ra, const double *pa, int b, const double *Rb,
+                       const double *pb, double *depth, double *dir_out, double *pos);
+int or_collide_pairs(const OrModel *m, const double Rb[][9], const double pb[][3], int ncon0, int *body1, int *body2,
+                     double *dist, double (*pos)[3], double (*nrm)[3], int *overflow);
 
 /* whole env step (tick + base teleport + ctrl map + sim step): main.py:119-129,192-195 */
 int or_env_step_batch(const OrModel *m, const double *params, int n, double *q, double *v, double *qpos,
@@ -159,7 +174,8 @@ int or_env_step_batch_walk(const OrModel *m, const double *params, int n, double
                            const double *cop_frames, const double *env_params, double *tau, double *dv, double *f,
                            int32_t *status, double *obs, int32_t *ncon, int32_t *con_geom, int nthreads,
                            const OrWalkTables *w /* NULL: references as given */, double *frames /* [n,2,12] or NULL */,
-                           double *rewdone /* [n,2] reward, done; or NULL */);
+                           double *rewdone /* [n,2] reward, done; or NULL */,
+                           const double *terrain /* [n,20] stepped-terrain tables (or_collide.c) or NULL */);
 
 #ifdef __cplusplus
 }

@@ -38,7 +38,8 @@ class OrSimInfo(C.Structure):
                 ("con_geom", C.c_int * MAXCON), ("con_vert", C.c_int * MAXCON),
                 ("con_dist", C.c_double * MAXCON), ("con_pos", C.c_double * (3 * MAXCON)),
                 ("efc_force", C.c_double * MAXEFC), ("qacc", C.c_double * NV), ("qacc_smooth", C.c_double * NV),
-                ("qfrc_bias", C.c_double * NV), ("qfrc_actuator", C.c_double * NV), ("M", C.c_double * (NV * NV))]
+                ("qfrc_bias", C.c_double * NV), ("qfrc_actuator", C.c_double * NV), ("M", C.c_double * (NV * NV)),
+                ("con_body1", C.c_int * MAXCON), ("con_frame", C.c_double * (3 * MAXCON)), ("flags", C.c_int)]
 
 
 class OrWalkTables(C.Structure):
@@ -171,20 +172,33 @@ class Oracle:
         return dict(tau=tau, dv=dv, f=f, obs=obs, status=st, iters=it.value)
 
     # ---- sim
-    def sim_step(self, qpos, qvel, ctrl, qacc_ws, envp=None):
+    def sim_step(self, qpos, qvel, ctrl, qacc_ws, envp=None, terrain=None, self_collision=False):
         assert all(x.dtype == np.float64 for x in (qpos, qvel, qacc_ws))
         ctrl = _f64(ctrl)
         info = OrSimInfo()
         ep = _f64(envp) if envp is not None else None
-        rc = self.lib.or_sim_step_env(self.m, _p(qpos), _p(qvel), _p(ctrl), _p(qacc_ws), _p(ep) if ep is not None else None,
-                                      C.byref(info))
+        tr = _f64(terrain) if terrain is not None else None
+        self.lib.or_sim_step_ext.restype = C.c_int
+        rc = self.lib.or_sim_step_ext(self.m, _p(qpos), _p(qvel), _p(ctrl), None, _p(qacc_ws), _p(ep) if ep is not None else None,
+                                      _p(tr) if tr is not None else None, int(bool(self_collision)), C.byref(info))
         nc, ne = info.ncon, info.nefc
         return dict(rc=rc, ncon=nc, nefc=ne, iters=info.solver_iter, con_geom=np.array(info.con_geom)[:nc],
+                    con_body1=np.array(info.con_body1)[:nc], con_frame=np.array(info.con_frame).reshape(MAXCON, 3)[:nc],
+                    flags=info.flags,
                     con_vert=np.array(info.con_vert)[:nc], con_dist=np.array(info.con_dist)[:nc],
                     con_pos=np.array(info.con_pos).reshape(MAXCON, 3)[:nc], efc_force=np.array(info.efc_force)[:ne],
                     qacc=np.array(info.qacc), qacc_smooth=np.array(info.qacc_smooth),
                     qfrc_bias=np.array(info.qfrc_bias), qfrc_actuator=np.array(info.qfrc_actuator),
                     M=np.array(info.M).reshape(NV, NV))
+
+    def mpr(self, a, Ra, pa, b, Rb, pb):
+        """or_mpr_penetration of hull a (placed at Ra, pa) and hull b: None or (depth, dir a->b, pos)."""
+        Ra, pa, Rb, pb = (_f64(np.asarray(x).reshape(-1)) for x in (Ra, pa, Rb, pb))
+        depth = C.c_double(0.0)
+        d, p = np.zeros(3), np.zeros(3)
+        self.lib.or_mpr_penetration.restype = C.c_int
+        hit = self.lib.or_mpr_penetration(self.m, int(a), _p(Ra), _p(pa), int(b), _p(Rb), _p(pb), C.byref(depth), _p(d), _p(p))
+        return (depth.value, d, p) if hit else None
 
     # ---- batch env step (all arrays float64, env-major, updated in place)
     def env_step_batch(self, params, st, nthreads=1, walk=None):
@@ -196,6 +210,7 @@ class Oracle:
         ep = st.get("env_params")
         fr = st.get("frames")
         rd = st.get("rewdone")
+        tr = st.get("terrain")
         if walk is not None and fr is None:
             raise ValueError("walking env step needs st['frames']")
         self.lib.or_env_step_batch_walk(
@@ -205,7 +220,7 @@ class Oracle:
             _p(st["tau"]), _p(st["dv"]), _p(st["f"]),
             _p(st["status"]), _p(st["obs"]), _p(st["ncon"]), _p(st["con_geom"]), int(nthreads),
             C.byref(walk.c) if walk is not None else None, _p(fr) if fr is not None else None,
-            _p(rd) if rd is not None else None)
+            _p(rd) if rd is not None else None, _p(tr) if tr is not None else None)
 
 
 def walk_update(lib, sched, t, frames, foot_ref, contact_ref, contact_active, com_ref):

@@ -383,9 +383,8 @@ def test_randomised_envs_config5_f64(oracle):
     n = 32
     wc = make(n)
     perturb(wc, 13)
-    wc.randomize(seed=2)
-    st = mirror(wc)
-    st["env_params"] = wc.env_params.cpu().numpy().copy()
+    wc.randomize(seed=2, step_height=0.0)   # the plane-only half; terrain steps: test_rough_terrain_config5_f64
+    st = _mirror_env(wc, mirror(wc))
     for i in range(40):
         wc.step()
         oracle.env_step_batch(wc.params, st, nthreads=8)
@@ -395,7 +394,7 @@ def test_randomised_envs_config5_f64(oracle):
     assert int(wc.ncon.max()) > 0
     # settle on the tilted floors without the teleport
     wc2 = make(8)
-    wc2.randomize(seed=3, tilt_deg=5.0)
+    wc2.randomize(seed=3, tilt_deg=5.0, step_height=0.0)
     wc2.qpos[:, 3:7] = torch.tensor([1.0, 0, 0, 0], dtype=wc2.dtype, device=wc2.device)
     wc2.qpos[:, 2] -= 0.002
     ep = wc2.env_params.cpu().numpy()
@@ -744,3 +743,114 @@ def test_reward_and_done_outputs(oracle):
     assert np.all(rd[ok, 1] == 0) and np.all(rd[ok, 0] > 0.5) and np.all(rd[ok, 0] < 1.0)
     assert torch.equal(wc.reward, wc.rows[:, 65]) and torch.equal(wc.done, wc.rows[:, 66])
     assert wc.gather_rows().shape == (n, 67) and wc.gather_rows().is_contiguous()
+
+
+def _mirror_env(wc, st):
+    if wc.env_params is not None:
+        st["env_params"] = wc.env_params.double().cpu().numpy().copy()
+    if wc.terrain is not None:
+        st["terrain"] = wc.terrain.double().cpu().numpy().copy()
+    return st
+
+
+def test_rough_terrain_config5_f64(oracle):
+    """The rough-terrain half of BASELINE configs[4]: per-env stepped floor (1 cm steps over a tilted plane) on top
+    of the mass / friction randomisation.  TSID-driven sim for 60 steps - contact (body, vertex) pairs bit-exact,
+    state to 1e-9 - then a free settle onto the steps."""
+    n = 32
+    wc = make(n)
+    perturb(wc, 17)
+    wc.randomize(seed=5, step_length=(0.02, 0.06))    # narrow strips: every sole straddles a step edge
+    assert wc.terrain is not None and float(wc.terrain[:, 4:].max()) == 0.01
+    st = _mirror_env(wc, mirror(wc))
+    seen = set()
+    for i in range(60):
+        wc.step()
+        oracle.env_step_batch(wc.params, st, nthreads=8)
+        assert np.array_equal(wc.ncon.cpu().numpy(), st["ncon"]), i
+        assert np.array_equal(wc.con_pairs.cpu().numpy(), st["con_geom"]), i
+        assert diff(wc.qpos, st["qpos"]) < 1e-9 and diff(wc.qvel, st["qvel"]) < 1e-6, i
+        seen.update(np.unique(st["ncon"]).tolist())
+    assert max(seen) >= 4 and len(seen) >= 3
+    # the same robots dropped onto their terrain, no teleport
+    wc2 = make(8)
+    wc2.randomize(seed=6, step_length=(0.02, 0.06))
+    wc2.qpos[:, 3:7] = torch.tensor([1.0, 0, 0, 0], dtype=wc2.dtype, device=wc2.device)
+    wc2.qpos[:, 2] += 0.004
+    ep, tr = wc2.env_params.cpu().numpy(), wc2.terrain.cpu().numpy()
+    qpos, qvel, ws = (x.cpu().numpy().copy() for x in (wc2.qpos, wc2.qvel, wc2.qacc_warmstart))
+    for i in range(120):
+        wc2.sim_step(teleport=False)
+        for e in range(8):
+            r = oracle.sim_step(qpos[e], qvel[e], np.zeros(20), ws[e], envp=ep[e], terrain=tr[e])
+            want = np.full(32, -1, dtype=np.int32)
+            want[:r["ncon"]] = (r["con_geom"] << 16) | r["con_vert"]
+            assert np.array_equal(wc2.con_pairs[e].cpu().numpy(), want), (i, e)
+    assert diff(wc2.qpos, qpos) < 1e-7 and diff(wc2.qvel, qvel) < 1e-4
+    assert int(wc2.ncon.min()) >= 1
+
+
+def _self_collision_poses(n, seed):
+    """sim joint angles U(-0.6, 0.6): a few robot<->robot hull pairs penetrate in most of them"""
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(n, 20, generator=g, dtype=torch.float64) - 0.5) * 1.2
+
+
+def test_robot_robot_hull_contacts_f64(oracle):
+    """a9's missing piece: the 170 robot<->robot candidate pairs (robot.xml:13-15 after the excludes of :18-52 and the
+    parent-child filter) collided as convex hulls (MPR, one contact per pair).  Robots held in the air in
+    self-penetrating poses: the (geom1 body, geom2 body) pair list bit-exact against the oracle, contact
+    geometry and the state after each step to the tolerance of two independent MPR runs."""
+    n = 24
+    wc = make(n, self_collision=True)
+    wc.qpos[:, 7:] = _self_collision_poses(n, 3).to(wc.device, wc.dtype)
+    wc.qpos[:, 3:7] = torch.tensor([1.0, 0, 0, 0], dtype=wc.dtype, device=wc.device)
+    wc.qpos[:, 2] = 1.0
+    qpos, qvel, ws = (x.cpu().numpy().copy() for x in (wc.qpos, wc.qvel, wc.qacc_warmstart))
+    n_hh = 0
+    cross = False
+    par = wc.model["mj_parent"]
+    anc = lambda b: {b} | (anc(int(par[b])) if par[b] >= 0 else set())
+    for i in range(12):
+        wc.sim_step(teleport=False)
+        for e in range(n):
+            r = oracle.sim_step(qpos[e], qvel[e], np.zeros(20), ws[e], self_collision=True)
+            want = np.full(32, -1, dtype=np.int32)
+            want[:r["ncon"]] = (r["con_geom"] << 16) | r["con_vert"]
+            assert np.array_equal(wc.con_pairs[e].cpu().numpy(), want), (i, e)       # pair list bit-exact
+            hh = r["con_body1"] >= 0
+            n_hh += int(hh.sum())
+            cross |= any(a not in anc(int(b)) and b not in anc(int(a)) for a, b in zip(r["con_body1"][hh], r["con_geom"][hh]))
+            assert r["flags"] == int(wc.info[e, 3]) & 8
+        assert diff(wc.qpos, qpos) < 1e-8 and diff(wc.qvel, qvel) < 1e-5, i
+    assert n_hh > 100 and cross     # both the tree-sparse and the dense Newton Hessian paths ran
+    assert bool(torch.isfinite(wc.qpos).all())
+    # the same poses without self-collision: no contact at all in the air
+    wc0 = make(n, self_collision=False)
+    wc0.qpos.copy_(torch.as_tensor(qpos, device=wc0.device))
+    wc0.qpos[:, 2] = 1.0
+    wc0.sim_step(teleport=False)
+    assert int(wc0.ncon.max()) == 0
+
+
+def test_fallen_robot_with_self_collision(oracle):
+    """the fallen-robot case: floor contacts up to the cap plus robot<->robot contacts, in the TSID-driven loop"""
+    n = 6
+    wc = make(n, self_collision=True)
+    quats = torch.tensor([[0.7071068, 0.7071068, 0, 0], [0.7071068, 0, 0.7071068, 0], [0.5, 0.5, 0.5, 0.5],
+                          [0.9238795, 0.3826834, 0, 0], [0.7071068, -0.7071068, 0, 0], [0.0, 1.0, 0, 0]], dtype=wc.dtype, device=wc.device)
+    wc.qpos[:, 3:7] = quats
+    wc.qpos[:, 2] = 0.09
+    wc.qpos[:, 7:] = _self_collision_poses(n, 9).to(wc.device, wc.dtype)
+    qpos, qvel, ws = (x.cpu().numpy().copy() for x in (wc.qpos, wc.qvel, wc.qacc_warmstart))
+    both = 0
+    for i in range(25):
+        wc.sim_step(teleport=False)
+        for e in range(n):
+            r = oracle.sim_step(qpos[e], qvel[e], np.zeros(20), ws[e], self_collision=True)
+            want = np.full(32, -1, dtype=np.int32)
+            want[:r["ncon"]] = (r["con_geom"] << 16) | r["con_vert"]
+            assert np.array_equal(wc.con_pairs[e].cpu().numpy(), want), (i, e)
+            both += int((r["con_body1"] >= 0).any() and (r["con_body1"] < 0).any())
+        assert diff(wc.qpos, qpos) < 1e-7 and diff(wc.qvel, qvel) < 1e-4, i
+    assert both > 20 and bool(torch.isfinite(wc.qpos).all())

@@ -41,7 +41,7 @@ def load():
     L.tsidb_step.argtypes = [vp] * 11 + [C.c_int] + [vp] * 4 + [C.c_int, vp]
     L.tsidb_rbd_terms.argtypes = [vp] * 10
     L.tsidb_lds_bytes.argtypes = [C.c_int, C.c_int]
-    L.tsidb_set_env_params.argtypes = [vp, vp]
+    L.tsidb_set_env_params.argtypes = [vp, vp, vp]
     L.tsidb_walk_update.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int] + [C.c_double] * 6 + [vp, vp, vp]
     for s in SYMBOLS:
         if s != "tsidb_last_error":

@@ -72,7 +72,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2))) void 
 
 template <typename T>
 __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2))) void k_sim(const DevModel<T> *__restrict__ mp, int n, const T *q_tsid, const T *v_tsid, T *qpos, T *qvel,
-                                              T *qacc_ws, const T *env_params, const T *motor_tau, T *qacc, int *ncon,
+                                              T *qacc_ws, const T *env_params, const T *terrain, const T *motor_tau, T *qacc, int *ncon,
                                               int *con, int *info) {
   __shared__ SimLds<T> L;
   const int e = blockIdx.x, lane = threadIdx.x;
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2))) void 
     }
   }
   sim_step_env<T>(*mp, L, lane, q_tsid ? q_tsid + E * NQ : nullptr, v_tsid ? v_tsid + E * NV : nullptr, qpos + E * NQ, qvel + E * NV, qacc_ws + E * NV,
-                  env_params ? env_params + E * 8 : nullptr, motor_tau ? motor_tau + E * NA : nullptr,
+                  env_params ? env_params + E * 8 : nullptr, terrain ? terrain + E * 20 : nullptr, motor_tau ? motor_tau + E * NA : nullptr,
                   qacc ? qacc + E * NV : nullptr, ncon ? ncon + e : nullptr, con ? con + E * MAXCON : nullptr,
                   info ? info + E * 4 : nullptr);
 }
@@ -365,7 +365,7 @@ struct tsidb_ctx {
   int *d_eadr = nullptr, *d_edge = nullptr;
   const void *com_ref = nullptr, *posture_ref = nullptr, *foot_ref = nullptr, *contact_ref = nullptr, *cop_frames = nullptr;
   const uint8_t *contact_active = nullptr;
-  const void *env_params = nullptr;
+  const void *env_params = nullptr, *terrain = nullptr;
   std::string err;
 };
 
@@ -505,6 +505,20 @@ static void build_model(tsidb_ctx *h, DevModel<T> &m) {
   m.hull_x = (const T *)h->d_hull;
   m.hull_y = m.hull_x + nvert;
   m.hull_z = m.hull_y + nvert;
+  {
+    const uint32_t np2 = b.count("mj_pairs");
+    if (np2 % 2 || np2 / 2 > MAXPAIR) throw std::string("model blob: too many candidate body pairs");
+    const int *pp = b.i32("mj_pairs", 0);
+    m.npair = (int)(np2 / 2);
+    for (int k = 0; k < m.npair; k++) {
+      m.pair_a[k] = pp[2 * k]; m.pair_b[k] = pp[2 * k + 1];
+      if (pp[2 * k] < 0 || pp[2 * k] >= NB || pp[2 * k + 1] < 0 || pp[2 * k + 1] >= NB) throw std::string("model blob: bad body pair");
+    }
+    const double *hc = b.f64("mj_hull_center", NB * 3), *hb = b.f64("mj_hull_box", NB * 6);
+    for (int i = 0; i < NB * 3; i++) m.hcen[i / 3][i % 3] = (T)hc[i];
+    for (int i = 0; i < NB * 6; i++) m.hbox[i / 6][i % 6] = (T)hb[i];
+    if (sizeof(T) == 4) for (int j = 0; j < NB; j++) for (int i = 3; i < 6; i++) m.hbox[j][i] = m.hbox[j][i] * (T)1.00001 + (T)1e-7;
+  }
   memcpy(m.chunk_adr, b.i32("mj_chunk_adr", NB + 1), sizeof m.chunk_adr);
   m.chunk_box = (const T *)h->d_box;
   m.hull_eadr = h->d_eadr;
@@ -552,9 +566,10 @@ static void upload_model(tsidb_ctx *h) {
   }                                      \
   return 0;
 
-extern "C" int tsidb_set_env_params(tsidb_handle h, const void *env_params) {
+extern "C" int tsidb_set_env_params(tsidb_handle h, const void *env_params, const void *terrain) {
   if (!h) return -1;
   h->env_params = env_params; // NULL restores the nominal model
+  h->terrain = terrain;       // NULL = no terrain steps
   return 0;
 }
 
@@ -580,7 +595,7 @@ template <typename T>
 static void launch_sim(tsidb_ctx *h, const void *q_tsid, const void *v_tsid, void *qpos, void *qvel, void *qacc_ws, void *qacc,
                        int32_t *ncon, int32_t *con, int32_t *info, hipStream_t s, const void *motor_tau = nullptr) {
   hipLaunchKernelGGL(k_sim<T>, dim3(h->num_envs), dim3(WAVE), 0, s, (const DevModel<T> *)h->d_model, h->num_envs,
-                     (const T *)q_tsid, (const T *)v_tsid, (T *)qpos, (T *)qvel, (T *)qacc_ws, (const T *)h->env_params, (const T *)motor_tau, (T *)qacc, ncon, con, info);
+                     (const T *)q_tsid, (const T *)v_tsid, (T *)qpos, (T *)qvel, (T *)qacc_ws, (const T *)h->env_params, (const T *)h->terrain, (const T *)motor_tau, (T *)qacc, ncon, con, info);
   HIP_OK(hipGetLastError());
 }
 

@@ -33,6 +33,8 @@ constexpr int LDF = 27;  // leading dimension of frame / CoM Jacobians
 constexpr int NOBS = 65;
 constexpr int NROW = 67; // obs row + reward + done when the caller's row stride has room for them
 constexpr int MAXCON = 32;
+constexpr int MAXHH = 12;    // robot<->robot contacts per env (the last slots of the contact list)
+constexpr int MAXPAIR = 192; // candidate body pairs (three rounds of one lane per pair)
 constexpr int MAXCHILD = 6;
 constexpr int WAVE = 64;
 
@@ -90,6 +92,10 @@ struct DevModel {
   int chunk_adr[NB + 1];             // 64-vertex spatial chunks per hull (k-d order) ...
   const T *chunk_box;                // ... with boxes [nchunk][6] = centre xyz, half extent xyz (device)
   const int *hull_eadr, *hull_edge;
+  // robot<->robot collision: candidate body pairs (after excludes and the parent-child filter), the hulls'
+  // centres of mass and body-frame bounding boxes (centre, half extents)
+  int npair, pair_a[MAXPAIR], pair_b[MAXPAIR];
+  T hcen[NB][3], hbox[NB][6];
 };
 
 // ------------------------------------------------------------------ small vector helpers

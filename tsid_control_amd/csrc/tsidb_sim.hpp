@@ -30,9 +30,17 @@ template <typename T>
 struct SimLds {
   Floor<T> fl; // per-env floor frame: read where needed instead of ten live registers per lane
   T S[NV][6];
-  union { // tree-pass scratch is dead once bias forces and M exist; the Newton loop reuses the space
+  union { // tree-pass scratch is dead once bias forces and M exist; collision and the Newton loop reuse the space
     struct { T V[NB][6], A[NB][6], f[NB][6], Yc[NB][10]; };
-    struct { T K[NB][21]; }; // per-body contact inertia (packed sym 6x6), composite over subtrees
+    struct {
+      T K[NB][21];      // per-body contact inertia (packed sym 6x6), composite over subtrees (Newton loop)
+      T hn[MAXHH][3];   // robot<->robot contacts: normal (geom1 -> geom2); written by the narrow phase
+      int hb1[MAXHH];   //                        body of geom1
+    };
+    struct {            // collision-time scratch, overlays K only
+      T terr[20];       // stepped-terrain table of this env
+      int pcand[64];    // candidate pairs that passed the mid phase
+    };
   };
   T M[NV * LDM];
   union { // body frames are needed until the contacts exist; per-contact inertias are folded into K
@@ -59,7 +67,9 @@ __device__ __forceinline__ int sym_idx(int i, int j) { // packed upper index of 
 // Eliminating leaves first (k = 25 .. 0) gives A = U U^T with U upper triangular and NO fill-in, so
 // only ancestor pairs are touched; MJ_DOFANC is a compile-time table, so the unrolled code simply
 // does not contain the zero updates.  U[i][k] ends up in lane i's a[k] (k >= i).
-template <typename T>
+// DENSE: a robot<->robot contact between two branches of the tree couples dofs that are not ancestor-related;
+// the same elimination order then runs over all pairs.
+template <typename T, bool DENSE>
 __device__ __forceinline__ T chol26_solve(T (&a)[NV], T rhs, int lane, bool &spd) {
   spd = true;
   T rd[NV]; // 1 / U[k][k], wave-uniform
@@ -73,7 +83,7 @@ __device__ __forceinline__ T chol26_solve(T (&a)[NV], T rhs, int lane, bool &spd
     a[k] = uik;
 #pragma unroll
     for (int j = 0; j < k; j++)
-      if ((MJ_DOFANC[k] >> j) & 1u) a[j] -= uik * rdlane(uik, j);
+      if (DENSE || ((MJ_DOFANC[k] >> j) & 1u)) a[j] -= uik * rdlane(uik, j);
   }
   // U y = rhs (k descending; lane k contributes y_k), then U^T x = y (k ascending, wave-uniform)
   T acc = rhs, y[NV];
@@ -88,7 +98,7 @@ __device__ __forceinline__ T chol26_solve(T (&a)[NV], T rhs, int lane, bool &spd
     T s0 = y[k];
 #pragma unroll
     for (int i = 0; i < k; i++)
-      if ((MJ_DOFANC[k] >> i) & 1u) s0 -= rdlane(a[k], i) * xs[i];
+      if (DENSE || ((MJ_DOFANC[k] >> i) & 1u)) s0 -= rdlane(a[k], i) * xs[i];
     xs[k] = s0 * rd[k];
     if (lane == k) x = xs[k];
   }
@@ -103,32 +113,426 @@ template <typename T> __device__ __forceinline__ T mulM(const SimLds<T> &L, cons
   return s;
 }
 
-// the 4 pyramid rows of contact `c` applied to generalized vector x (LDS): J_row x
+// mju_makeFrame: tangents of a contact frame from its normal (t1 from y unless |n_y| >= 0.5, t2 = n x t1)
+template <typename T> __device__ __forceinline__ void make_frame(const T *n, T *t1, T *t2) {
+  T t[3] = {0, 0, 0};
+  if (fabs(n[1]) < T(0.5)) t[1] = 1; else t[2] = 1;
+  const T dn = dot3(n, t);
+  T nn = 0;
+#pragma unroll
+  for (int i = 0; i < 3; i++) { t1[i] = t[i] - dn * n[i]; nn += t1[i] * t1[i]; }
+  nn = T(1) / sqrt(nn);
+#pragma unroll
+  for (int i = 0; i < 3; i++) t1[i] *= nn;
+  cross3(n, t1, t2);
+}
+
+// frame (normal, tangents) and geom1 body of contact c: floor contacts [0, nfl) share the floor frame and have
+// no geom1 body (-1); robot<->robot contacts keep their normal in LDS and rebuild the tangents
 template <typename T>
-__device__ __forceinline__ void contact_rows(const DevModel<T> &m, const SimLds<T> &L, const Floor<T> &fl, int c, const T *x,
+__device__ __forceinline__ int contact_frame(const SimLds<T> &L, int c, int nfl, T *n, T *t1, T *t2) {
+  if (c < nfl) {
+#pragma unroll
+    for (int i = 0; i < 3; i++) { n[i] = L.fl.n[i]; t1[i] = L.fl.t1[i]; t2[i] = L.fl.t2[i]; }
+    return -1;
+  }
+#pragma unroll
+  for (int i = 0; i < 3; i++) n[i] = L.hn[c - nfl][i];
+  make_frame(n, t1, t2);
+  return L.hb1[c - nfl];
+}
+
+// the 4 pyramid rows of contact `c` applied to generalized vector x (LDS): J_row x, with J = point Jacobian of
+// geom2's body minus that of geom1's body (the floor does not move)
+template <typename T>
+__device__ __forceinline__ void contact_rows(const DevModel<T> &m, const SimLds<T> &L, int nfl, int c, const T *x,
                                              T mu, T *out) {
+  T n[3], t1[3], t2[3];
+  const int b1 = contact_frame(L, c, nfl, n, t1, t2);
   T tw[6] = {0, 0, 0, 0, 0, 0};
-  for (unsigned mk = L.anc[L.cbody[c]]; mk; mk &= mk - 1) {
-    const int a = __ffs(mk) - 1;
-    if (a == 0) {
+  const unsigned m2 = L.anc[L.cbody[c]], m1 = b1 >= 0 ? L.anc[b1] : 0u;
 #pragma unroll
-      for (int k = 0; k < 6; k++) {
-        const T xk = x[k];
+  for (int side = 0; side < 2; side++) {
+    const T sg = side == 0 ? T(1) : T(-1);
+    for (unsigned mk = side == 0 ? (m2 & ~m1) : (m1 & ~m2); mk; mk &= mk - 1) {
+      const int a = __ffs(mk) - 1;
+      if (a == 0) {
 #pragma unroll
-        for (int i = 0; i < 6; i++) tw[i] += L.S[k][i] * xk;
+        for (int k = 0; k < 6; k++) {
+          const T xk = sg * x[k];
+#pragma unroll
+          for (int i = 0; i < 6; i++) tw[i] += L.S[k][i] * xk;
+        }
+      } else {
+        const T xk = sg * x[5 + a];
+#pragma unroll
+        for (int i = 0; i < 6; i++) tw[i] += L.S[5 + a][i] * xk;
       }
-    } else {
-      const T xk = x[5 + a];
-#pragma unroll
-      for (int i = 0; i < 6; i++) tw[i] += L.S[5 + a][i] * xk;
     }
   }
   T wxr[3];
   cross3(tw + 3, L.cr[c], wxr);
   const T u[3] = {tw[0] + wxr[0], tw[1] + wxr[1], tw[2] + wxr[2]};
-  const T un = dot3(fl.n, u), u1 = dot3(fl.t1, u), u2 = dot3(fl.t2, u);
+  const T un = dot3(n, u), u1 = dot3(t1, u), u2 = dot3(t2, u);
   out[0] = un + mu * u1; out[1] = un - mu * u1; out[2] = un + mu * u2; out[3] = un - mu * u2;
 }
+
+// ------------------------------------------------------------------ collision helpers
+// stepped terrain (BASELINE.json configs[4]; no reference counterpart): the floor surface is the plane n.x = d
+// raised along n by heights[cell & 15], cell = floor((dir . x_world_xy - phase) * inv_len).
+// Table: dir_x, dir_y, phase, inv_len, heights[16] (staged in LDS for the collision phase).
+template <typename T> __device__ __forceinline__ T terrain_h(const T *terr, T X, T Y) {
+  const T u = terr[0] * X + terr[1] * Y;
+  const int cell = (int)floor((u - terr[2]) * terr[3]) & 15;
+  return terr[4 + cell];
+}
+
+// Lowest-index vertex of body b's hull within `tie` of the minimum of  r . v + pz  [- terrain height under the
+// vertex], v in the body frame.  Exact pruned search: the hull's vertices are stored in k-d order, 64 per chunk,
+// each chunk with a bounding box; a chunk can hold the minimum (or a vertex within the tie tolerance of it) only
+// if its lower bound does not exceed the best value found so far, and every such chunk is scanned, so the result
+// equals the exhaustive search.  TERR: Rw = the body's world rotation, (px, py) = its world position; the lower
+// bound then subtracts the highest terrain cell the chunk's box can reach.
+template <typename T, bool TERR>
+__device__ __forceinline__ int hull_argmin(const DevModel<T> &m, int lane, int b, T r6, T r7, T r8, T pz, T tie, const T *terr,
+                                           const T *Rw, T px, T py, T hmax_all, T &zmin_out) {
+  const T INF = Eps<T>::inf;
+  const int v0 = m.hull_adr[b], v1 = m.hull_adr[b + 1];
+  const int c0 = m.chunk_adr[b], nch = m.chunk_adr[b + 1] - c0;
+  T zlb = INF;
+  if (lane < nch) {
+    const T *bx = m.chunk_box + 6 * (c0 + lane);
+    zlb = r6 * bx[0] + r7 * bx[1] + r8 * bx[2] + pz - (fabs(r6) * bx[3] + fabs(r7) * bx[4] + fabs(r8) * bx[5]);
+    zlb -= fabs(zlb) * T(4) * Eps<T>::v; // rounding slack: never prune a chunk that could matter
+    if constexpr (TERR) {
+      // terrain cells the box can reach along the step direction
+      const T a0 = terr[0] * Rw[0] + terr[1] * Rw[3], a1 = terr[0] * Rw[1] + terr[1] * Rw[4], a2 = terr[0] * Rw[2] + terr[1] * Rw[5];
+      const T uc = a0 * bx[0] + a1 * bx[1] + a2 * bx[2] + terr[0] * px + terr[1] * py;
+      const T ext = fabs(a0) * bx[3] + fabs(a1) * bx[4] + fabs(a2) * bx[5] + T(1e-6);
+      const int k0 = (int)floor((uc - ext - terr[2]) * terr[3]), k1 = (int)floor((uc + ext - terr[2]) * terr[3]);
+      T hm = hmax_all;
+      if (k1 - k0 < 15) {
+        hm = terr[4 + (k0 & 15)];
+        for (int k = k0 + 1; k <= k1; k++) { const T hk = terr[4 + (k & 15)]; hm = hk > hm ? hk : hm; }
+      }
+      zlb -= hm;
+    }
+  }
+  auto vert_val = [&](int i) -> T {
+    const T x = m.hull_x[i], y = m.hull_y[i], z = m.hull_z[i];
+    T val = r6 * x + r7 * y + r8 * z + pz;
+    if constexpr (TERR) val -= terrain_h(terr, Rw[0] * x + Rw[1] * y + Rw[2] * z + px, Rw[3] * x + Rw[4] * y + Rw[5] * z + py);
+    return val;
+  };
+  unsigned long long scanned = 0;
+  T zmin = INF;
+  {
+    T zl = zlb;
+    int ci = lane;
+    wave_argmin(zl, ci);
+    unsigned long long pend = 1ull << ci;
+    while (pend) {
+      const int c = __ffsll((long long)pend) - 1;
+      const int i = v0 + WAVE * c + lane;
+      T z = INF;
+      if (i < v1) z = vert_val(i);
+      const T zc2 = wave_min(z);
+      zmin = zc2 < zmin ? zc2 : zmin;
+      scanned |= 1ull << c;
+      pend = __ballot(lane < nch && zlb <= zmin + tie) & ~scanned;
+    }
+  }
+  zmin_out = zmin;
+  // lowest-index vertex within the tie tolerance of the minimum (chunks are in index order)
+  int best = 0x7fffffff;
+  const T zt = zmin + tie;
+  for (unsigned long long sm = scanned; sm && best == 0x7fffffff; sm &= sm - 1) {
+    const int c = __ffsll((long long)sm) - 1;
+    const int i = v0 + WAVE * c + lane;
+    int cand = 0x7fffffff;
+    if (i < v1 && vert_val(i) <= zt) cand = i;
+    best = wave_min_int(cand);
+  }
+  return best;
+}
+
+template <typename T> __device__ __forceinline__ bool normalize3(T *a) {
+  const T n2 = dot3(a, a);
+  if (!(n2 > 0)) return false;
+  const T r = T(1) / sqrt(n2);
+  a[0] *= r; a[1] *= r; a[2] *= r;
+  return true;
+}
+
+// squared distance from the origin to triangle (a, b, c) and the closest point (Ericson 5.1.5)
+template <typename T> __device__ __forceinline__ T origin_tri_closest(const T *a, const T *b, const T *c, T *q) {
+  T ab[3], ac[3];
+#pragma unroll
+  for (int i = 0; i < 3; i++) { ab[i] = b[i] - a[i]; ac[i] = c[i] - a[i]; }
+  const T d1 = -dot3(ab, a), d2 = -dot3(ac, a);
+  if (d1 <= 0 && d2 <= 0) { q[0] = a[0]; q[1] = a[1]; q[2] = a[2]; return dot3(q, q); }
+  const T d3 = -dot3(ab, b), d4 = -dot3(ac, b);
+  if (d3 >= 0 && d4 <= d3) { q[0] = b[0]; q[1] = b[1]; q[2] = b[2]; return dot3(q, q); }
+  const T vc = d1 * d4 - d3 * d2;
+  if (vc <= 0 && d1 >= 0 && d3 <= 0) {
+    const T t = d1 / (d1 - d3);
+#pragma unroll
+    for (int i = 0; i < 3; i++) q[i] = a[i] + t * ab[i];
+    return dot3(q, q);
+  }
+  const T d5 = -dot3(ab, c), d6 = -dot3(ac, c);
+  if (d6 >= 0 && d5 <= d6) { q[0] = c[0]; q[1] = c[1]; q[2] = c[2]; return dot3(q, q); }
+  const T vb = d5 * d2 - d1 * d6;
+  if (vb <= 0 && d2 >= 0 && d6 <= 0) {
+    const T t = d2 / (d2 - d6);
+#pragma unroll
+    for (int i = 0; i < 3; i++) q[i] = a[i] + t * ac[i];
+    return dot3(q, q);
+  }
+  const T va = d3 * d6 - d5 * d4;
+  if (va <= 0 && (d4 - d3) >= 0 && (d5 - d6) >= 0) {
+    const T t = (d4 - d3) / ((d4 - d3) + (d5 - d6));
+#pragma unroll
+    for (int i = 0; i < 3; i++) q[i] = b[i] + t * (c[i] - b[i]);
+    return dot3(q, q);
+  }
+  const T den = T(1) / (va + vb + vc), v = vb * den, w = vc * den;
+#pragma unroll
+  for (int i = 0; i < 3; i++) q[i] = a[i] + ab[i] * v + ac[i] * w;
+  return dot3(q, q);
+}
+
+// Penetration of the convex hulls of bodies a (geom1) and b (geom2): Minkowski Portal Refinement on A - B, what
+// MuJoCo's mjc_Convex runs for mesh pairs (libccd ccdMPRPenetration; Snethen 2008) - portal discovery from the
+// interior point centre(a) - centre(b), refinement until the portal stops advancing, depth = distance from the
+// origin to the final portal, contact point from the portal's barycentric weights; one contact per pair.
+// The scalar state is wave-uniform (every lane computes it); the wave's parallelism goes into the two hull
+// support searches per step (hull_argmin: chunk bounds on the lanes, then 64 vertices per scan).
+// Placements L.R / L.p are relative to the base origin O; so is pos.  Returns true with depth >= 0, unit dir
+// (geom1 -> geom2) and pos.
+template <typename T>
+__device__ __forceinline__ bool mpr_penetration(const DevModel<T> &m, const SimLds<T> &L, int lane, int a, int b, T &depth, T *dir_out, T *pos) {
+  const T TOL = sizeof(T) == 8 ? T(1e-10) : T(2e-6), TIE = sizeof(T) == 8 ? T(1e-12) : T(1e-7);
+  const T TINY2 = sizeof(T) == 8 ? T(1e-30) : T(1e-20), SIDE = sizeof(T) == 8 ? T(1e-14) : T(1e-9);
+  constexpr int MAXIT = 64;
+  const T *Ra = L.R[a], *Rb = L.R[b], *pa = L.p[a], *pb = L.p[b];
+  const int va0 = m.hull_adr[a], vb0 = m.hull_adr[b];
+  auto wvert = [&](const T *R, const T *p, int i, T *w) {
+    const T v[3] = {m.hull_x[i], m.hull_y[i], m.hull_z[i]};
+    mat3vec(R, v, w);
+    w[0] += p[0]; w[1] += p[1]; w[2] += p[2];
+  };
+  // support point of A - B along d: vertex of A farthest along d minus vertex of B farthest along -d
+  auto support = [&](const T *d, T *v, int &ia, int &ib) {
+    T ra[3], rb[3], zz, wa[3], wb[3];
+    mat3Tvec(Ra, d, ra);
+    mat3Tvec(Rb, d, rb);
+    ia = hull_argmin<T, false>(m, lane, a, -ra[0], -ra[1], -ra[2], T(0), TIE, nullptr, nullptr, T(0), T(0), T(0), zz);
+    ib = hull_argmin<T, false>(m, lane, b, rb[0], rb[1], rb[2], T(0), TIE, nullptr, nullptr, T(0), T(0), T(0), zz);
+    wvert(Ra, pa, ia, wa);
+    wvert(Rb, pb, ib, wb);
+    v[0] = wa[0] - wb[0]; v[1] = wa[1] - wb[1]; v[2] = wa[2] - wb[2];
+  };
+  T ca[3], cb[3], v0[3], v1[3], v2[3], v3[3], v4[3], dir[3], e1[3], e2[3];
+  int i1a = 0, i1b = 0, i2a = 0, i2b = 0, i3a = 0, i3b = 0, i4a = 0, i4b = 0;
+  mat3vec(Ra, m.hcen[a], ca);
+  mat3vec(Rb, m.hcen[b], cb);
+#pragma unroll
+  for (int i = 0; i < 3; i++) { ca[i] += pa[i]; cb[i] += pb[i]; v0[i] = ca[i] - cb[i]; }
+  if (dot3(v0, v0) < TINY2) { v0[0] = sizeof(T) == 8 ? T(1e-10) : T(1e-6); v0[1] = 0; v0[2] = 0; }
+  // ---- portal discovery
+#pragma unroll
+  for (int i = 0; i < 3; i++) dir[i] = -v0[i];
+  normalize3(dir);
+  support(dir, v1, i1a, i1b);
+  if (dot3(v1, dir) <= 0) return false;
+  cross3(v0, v1, dir);
+  if (dot3(dir, dir) < TINY2) { // the origin lies on the ray v0 -> v1: penetration along that ray
+    const T d1 = sqrt(dot3(v1, v1));
+    if (!(d1 > 0)) return false;
+    depth = d1;
+    T wa[3], wb[3];
+    wvert(Ra, pa, i1a, wa);
+    wvert(Rb, pb, i1b, wb);
+#pragma unroll
+    for (int i = 0; i < 3; i++) { dir_out[i] = v1[i] / d1; pos[i] = T(0.5) * (wa[i] + wb[i]); }
+    return true;
+  }
+  normalize3(dir);
+  support(dir, v2, i2a, i2b);
+  if (dot3(v2, dir) <= 0) return false;
+#pragma unroll
+  for (int i = 0; i < 3; i++) { e1[i] = v1[i] - v0[i]; e2[i] = v2[i] - v0[i]; }
+  cross3(e1, e2, dir);
+  normalize3(dir);
+  if (dot3(dir, v0) > 0) { // orient the portal normal away from v0
+#pragma unroll
+    for (int i = 0; i < 3; i++) { const T t = v1[i]; v1[i] = v2[i]; v2[i] = t; dir[i] = -dir[i]; }
+    int t = i1a; i1a = i2a; i2a = t;
+    t = i1b; i1b = i2b; i2b = t;
+  }
+  for (int it = 0;; it++) {
+    if (it > MAXIT) return false;
+    support(dir, v3, i3a, i3b);
+    if (dot3(v3, dir) <= 0) return false;
+    bool cont = false;
+    cross3(v1, v3, e1);
+    if (dot3(e1, v0) < -SIDE) { // origin outside (v1, v0, v3)
+#pragma unroll
+      for (int i = 0; i < 3; i++) v2[i] = v3[i];
+      i2a = i3a; i2b = i3b;
+      cont = true;
+    }
+    if (!cont) {
+      cross3(v3, v2, e1);
+      if (dot3(e1, v0) < -SIDE) { // origin outside (v3, v0, v2)
+#pragma unroll
+        for (int i = 0; i < 3; i++) v1[i] = v3[i];
+        i1a = i3a; i1b = i3b;
+        cont = true;
+      }
+    }
+    if (!cont) break;
+#pragma unroll
+    for (int i = 0; i < 3; i++) { e1[i] = v1[i] - v0[i]; e2[i] = v2[i] - v0[i]; }
+    cross3(e1, e2, dir);
+    normalize3(dir);
+  }
+  // ---- portal refinement until the portal reaches the surface of A - B; the origin must end up inside it
+  bool inside = false;
+  for (int it = 0;; it++) {
+#pragma unroll
+    for (int i = 0; i < 3; i++) { e1[i] = v2[i] - v1[i]; e2[i] = v3[i] - v1[i]; }
+    cross3(e1, e2, dir);
+    normalize3(dir);
+    if (dot3(dir, v1) >= 0) inside = true;
+    support(dir, v4, i4a, i4b);
+    const T d4 = dot3(v4, dir);
+    T adv = d4 - dot3(v1, dir);
+    const T adv2 = d4 - dot3(v2, dir), adv3 = d4 - dot3(v3, dir);
+    adv = adv2 < adv ? adv2 : adv;
+    adv = adv3 < adv ? adv3 : adv;
+    if (!inside && d4 < 0) return false; // the origin is beyond the support plane: separated
+    if (adv <= TOL || it >= MAXIT) {
+      if (!inside) return false;
+      break;
+    }
+    // expand the portal with v4: replace the vertex that keeps the origin's ray inside
+    cross3(v4, v0, e1);
+    if (dot3(v1, e1) > 0) {
+      if (dot3(v2, e1) > 0) {
+#pragma unroll
+        for (int i = 0; i < 3; i++) v1[i] = v4[i];
+        i1a = i4a; i1b = i4b;
+      } else {
+#pragma unroll
+        for (int i = 0; i < 3; i++) v3[i] = v4[i];
+        i3a = i4a; i3b = i4b;
+      }
+    } else {
+      if (dot3(v3, e1) > 0) {
+#pragma unroll
+        for (int i = 0; i < 3; i++) v2[i] = v4[i];
+        i2a = i4a; i2b = i4b;
+      } else {
+#pragma unroll
+        for (int i = 0; i < 3; i++) v1[i] = v4[i];
+        i1a = i4a; i1b = i4b;
+      }
+    }
+  }
+  // ---- penetration: closest point of the final portal to the origin
+  T q[3];
+  const T d2 = origin_tri_closest(v1, v2, v3, q);
+  depth = sqrt(d2);
+#pragma unroll
+  for (int i = 0; i < 3; i++) { e1[i] = v2[i] - v1[i]; e2[i] = v3[i] - v1[i]; }
+  cross3(e1, e2, dir);
+  normalize3(dir);
+  if (depth > SIDE) {
+#pragma unroll
+    for (int i = 0; i < 3; i++) dir_out[i] = q[i] / depth;
+  } else {
+#pragma unroll
+    for (int i = 0; i < 3; i++) dir_out[i] = dir[i];
+  }
+  // ---- contact point: barycentric weights of the origin's ray in the portal
+  T bw[4], t1[3];
+  cross3(v1, v2, t1); bw[0] = dot3(t1, v3);
+  cross3(v3, v2, t1); bw[1] = dot3(t1, v0);
+  cross3(v0, v1, t1); bw[2] = dot3(t1, v3);
+  cross3(v2, v1, t1); bw[3] = dot3(t1, v0);
+  T sum = bw[0] + bw[1] + bw[2] + bw[3];
+  if (sum <= 0) {
+    bw[0] = 0;
+    cross3(v2, v3, t1); bw[1] = dot3(t1, dir);
+    cross3(v3, v1, t1); bw[2] = dot3(t1, dir);
+    cross3(v1, v2, t1); bw[3] = dot3(t1, dir);
+    sum = bw[1] + bw[2] + bw[3];
+  }
+  T p1[3], p2[3], wa[3], wb[3];
+#pragma unroll
+  for (int i = 0; i < 3; i++) { p1[i] = bw[0] * ca[i]; p2[i] = bw[0] * cb[i]; }
+  wvert(Ra, pa, i1a, wa); wvert(Rb, pb, i1b, wb);
+#pragma unroll
+  for (int i = 0; i < 3; i++) { p1[i] += bw[1] * wa[i]; p2[i] += bw[1] * wb[i]; }
+  wvert(Ra, pa, i2a, wa); wvert(Rb, pb, i2b, wb);
+#pragma unroll
+  for (int i = 0; i < 3; i++) { p1[i] += bw[2] * wa[i]; p2[i] += bw[2] * wb[i]; }
+  wvert(Ra, pa, i3a, wa); wvert(Rb, pb, i3b, wb);
+#pragma unroll
+  for (int i = 0; i < 3; i++) { p1[i] += bw[3] * wa[i]; p2[i] += bw[3] * wb[i]; }
+#pragma unroll
+  for (int i = 0; i < 3; i++) pos[i] = T(0.5) * (p1[i] + p2[i]) / sum;
+  (void)va0; (void)vb0;
+  return true;
+}
+
+// mid phase for one candidate pair (one lane per pair): bounding spheres, then the 15-axis separating-axis test
+// on the hulls' body-frame boxes
+template <typename T>
+__device__ __forceinline__ bool pair_may_touch(const DevModel<T> &m, const SimLds<T> &L, int a, int b) {
+  const T *Ra = L.R[a], *Rb = L.R[b];
+  T ca[3], cb[3], d[3];
+  mat3vec(Ra, m.rbound[a], ca);
+  mat3vec(Rb, m.rbound[b], cb);
+#pragma unroll
+  for (int i = 0; i < 3; i++) d[i] = (ca[i] + L.p[a][i]) - (cb[i] + L.p[b][i]);
+  const T rr = m.rbound[a][3] + m.rbound[b][3];
+  if (dot3(d, d) > rr * rr) return false;
+  mat3vec(Ra, m.hbox[a], ca);
+  mat3vec(Rb, m.hbox[b], cb);
+#pragma unroll
+  for (int i = 0; i < 3; i++) d[i] = (cb[i] + L.p[b][i]) - (ca[i] + L.p[a][i]);
+  const T *ha = m.hbox[a] + 3, *hb = m.hbox[b] + 3;
+  T Rm[3][3], A[3][3], t[3];
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    t[i] = Ra[i] * d[0] + Ra[3 + i] * d[1] + Ra[6 + i] * d[2];
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      Rm[i][j] = Ra[i] * Rb[j] + Ra[3 + i] * Rb[3 + j] + Ra[6 + i] * Rb[6 + j];
+      A[i][j] = fabs(Rm[i][j]) + (sizeof(T) == 8 ? T(1e-12) : T(1e-6));
+    }
+  }
+  bool sep = false;
+#pragma unroll
+  for (int i = 0; i < 3; i++) sep |= fabs(t[i]) > ha[i] + A[i][0] * hb[0] + A[i][1] * hb[1] + A[i][2] * hb[2];
+#pragma unroll
+  for (int j = 0; j < 3; j++)
+    sep |= fabs(t[0] * Rm[0][j] + t[1] * Rm[1][j] + t[2] * Rm[2][j]) > ha[0] * A[0][j] + ha[1] * A[1][j] + ha[2] * A[2][j] + hb[j];
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+      const T ra = ha[i1] * A[i2][j] + ha[i2] * A[i1][j], rb = hb[j1] * A[i][j2] + hb[j2] * A[i][j1];
+      sep |= fabs(t[i2] * Rm[i1][j] - t[i1] * Rm[i2][j]) > ra + rb;
+    }
+  return !sep;
+}
+
+template <typename T> __device__ __forceinline__ unsigned bodyanc_of(const DevModel<T> &m, int b) { return m.mj_anc[b]; }
 
 // per-lane constraint bookkeeping (friction row of dof `lane`, contact `lane`)
 template <typename T>
@@ -162,7 +566,7 @@ __device__ __forceinline__ void rows_eval(const RowState<T> &rs, T alpha, T &c, 
 
 template <typename T>
 __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L, int lane, const T *q_tsid, const T *v_tsid, T *qpos_g, T *qvel_g,
-                             T *qacc_ws_g, const T *envp, const T *motor_tau, T *qacc_out, int *ncon_out, int *con_out,
+                             T *qacc_ws_g, const T *envp, const T *terr_g, const T *motor_tau, T *qacc_out, int *ncon_out, int *con_out,
                              int *info) {
   // per-env randomisation (BASELINE config 5), NULL = nominal: mass scale, contact friction, floor plane
   const T mscale = envp ? envp[0] : T(1);
@@ -367,14 +771,22 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
 #pragma unroll
   for (int j = 0; j < NV; j++) arow[j] = lane < NV ? L.M[lane * LDM + j] : T(0);
   bool spd;
-  const T qas = chol26_solve(arow, qfs, lane, spd);
+  const T qas = chol26_solve<T, false>(arow, qfs, lane, spd);
   int fail = spd ? 0 : 1;
 
   TSIDB_STAMP(18);
-  // ---- collision: floor plane (n.x = d; nominal z = 0) against each body's convex hull
+  // ---- collision: floor (plane n.x = d, nominal z = 0, optionally with terrain steps) against each body's hull
   const T margin = 0, tie_tol = m.opt[6];
   const T Ow[3] = {L.qpos[0], L.qpos[1], L.qpos[2]};
-  const T nO = dot3(fl.n, Ow) - fl.d; // signed distance of the base origin O to the floor
+  const T nO = dot3(fl.n, Ow) - fl.d; // signed distance of the base origin O to the floor plane
+  const bool has_terr = terr_g != nullptr;
+  T hmax_all = 0;
+  if (has_terr) { // the tree-pass scratch is dead: stage this env's terrain table over it
+    if (lane < 20) L.terr[lane] = terr_g[lane];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; i++) hmax_all = L.terr[4 + i] > hmax_all ? L.terr[4 + i] : hmax_all;
+  }
   int ncon = 0;
   // bounding-sphere pretest for all bodies at once (lane = body, whose rotation and position are still in
   // this lane's registers); only the bodies that can reach the floor enter the support search, in body order
@@ -387,7 +799,7 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
       const T c8 = fl.n[0] * Rb[2] + fl.n[1] * Rb[5] + fl.n[2] * Rb[8];
       const T pzl = dot3(fl.n, pb) + nO;
       const T zc = c6 * m.rbound[lane][0] + c7 * m.rbound[lane][1] + c8 * m.rbound[lane][2] + pzl;
-      near = !(zc - m.rbound[lane][3] > margin);
+      near = !(zc - m.rbound[lane][3] - hmax_all > margin);
     }
     cand_bodies = __ballot(near);
   }
@@ -399,54 +811,13 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
     const T r7 = fl.n[0] * Rb[1] + fl.n[1] * Rb[4] + fl.n[2] * Rb[7];
     const T r8 = fl.n[0] * Rb[2] + fl.n[1] * Rb[5] + fl.n[2] * Rb[8];
     const T pz = dot3(fl.n, L.p[b]) + nO;
-    const int v0 = m.hull_adr[b], v1 = m.hull_adr[b + 1];
-    // exact pruned support search: the hull's vertices are stored in k-d order, 64 per chunk, each
-    // chunk with a bounding box.  A chunk can hold the lowest vertex (or one within the tie
-    // tolerance of it) only if the box's lower bound along the floor normal does not exceed the best
-    // z found so far; every such chunk is scanned, so the result equals the exhaustive search.
-    const int c0 = m.chunk_adr[b], nch = m.chunk_adr[b + 1] - c0;
-    T zlb = INF;
-    if (lane < nch) {
-      const T *bx = m.chunk_box + 6 * (c0 + lane);
-      zlb = r6 * bx[0] + r7 * bx[1] + r8 * bx[2] + pz - (fabs(r6) * bx[3] + fabs(r7) * bx[4] + fabs(r8) * bx[5]);
-      zlb -= fabs(zlb) * T(4) * Eps<T>::v; // rounding slack: never prune a chunk that could matter
-    }
-    unsigned long long scanned = 0;
-    T zmin = INF;
-    T zmine = 0; // this lane's vertex z in the chunk being scanned
-    {
-      T zl = zlb;
-      int ci = lane;
-      wave_argmin(zl, ci);
-      unsigned long long pend = 1ull << ci;
-      while (pend) {
-        const int c = __ffsll((long long)pend) - 1;
-        const int i = v0 + WAVE * c + lane;
-        T z = INF;
-        if (i < v1) z = r6 * m.hull_x[i] + r7 * m.hull_y[i] + r8 * m.hull_z[i] + pz;
-        const T zc2 = wave_min(z);
-        zmin = zc2 < zmin ? zc2 : zmin;
-        scanned |= 1ull << c;
-        pend = __ballot(lane < nch && zlb <= zmin + tie_tol) & ~scanned;
-      }
-    }
-    (void)zmine;
+    const int v0 = m.hull_adr[b];
+    T zmin;
+    const int best = has_terr ? hull_argmin<T, true>(m, lane, b, r6, r7, r8, pz, tie_tol, L.terr, Rb, L.p[b][0] + Ow[0],
+                                                     L.p[b][1] + Ow[1], hmax_all, zmin)
+                              : hull_argmin<T, false>(m, lane, b, r6, r7, r8, pz, tie_tol, nullptr, nullptr, T(0), T(0), T(0), zmin);
     if (zmin > margin) continue;
-    // lowest-index vertex within the tie tolerance of the minimum (chunks are in index order)
-    int best = 0x7fffffff;
-    {
-      const T zt = zmin + tie_tol;
-      for (unsigned long long sm = scanned; sm && best == 0x7fffffff; sm &= sm - 1) {
-        const int c = __ffsll((long long)sm) - 1;
-        const int i = v0 + WAVE * c + lane;
-        int cand = 0x7fffffff;
-        if (i < v1) {
-          const T z = r6 * m.hull_x[i] + r7 * m.hull_y[i] + r8 * m.hull_z[i] + pz;
-          if (z <= zt) cand = i;
-        }
-        best = wave_min_int(cand);
-      }
-    }
+    // the support vertex, then its hull-graph neighbours within the margin
     const int e0 = m.hull_eadr[best];
     int nnb = m.hull_eadr[best + 1] - e0;
     nnb = nnb > WAVE - 1 ? WAVE - 1 : nnb;
@@ -459,6 +830,7 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
       mat3vec(Rb, vv, w);
       w[0] += L.p[b][0]; w[1] += L.p[b][1]; w[2] += L.p[b][2]; // relative to O
       wd = dot3(fl.n, w) + nO;
+      if (has_terr) wd -= terrain_h(L.terr, w[0] + Ow[0], w[1] + Ow[1]);
       keep = lane == 0 || wd <= margin;
     }
     const unsigned long long mask = __ballot(keep);
@@ -474,13 +846,52 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
     ncon += __popcll(mask);
     ncon = ncon > MAXCON ? MAXCON : ncon;
   }
+  const int nfl = ncon; // contacts [0, nfl) are floor contacts (shared frame), [nfl, ncon) robot<->robot ones
+  // ---- collision: robot<->robot convex-hull pairs (robot.xml:13-15 after the excludes of :18-52 and the
+  //      parent-child filter): mid phase one lane per pair, narrow phase (MPR) one pair at a time on the wave
+  bool hh_cross = false; // some robot<->robot contact couples two branches of the tree (dense Newton Hessian)
+  if (m.params[P_SELF_COLLISION] != 0) {
+    __syncthreads(); // the terrain table is dead; pcand overlays it
+    int ncand = 0;
+    bool over = false;
+    for (int k0 = 0; k0 < m.npair; k0 += WAVE) {
+      const int k = k0 + lane;
+      bool may = false;
+      if (k < m.npair) may = pair_may_touch(m, L, m.pair_a[k], m.pair_b[k]);
+      const unsigned long long mk = __ballot(may);
+      const int pos = ncand + __popcll(mk & ((1ull << lane) - 1ull));
+      if (may && pos < WAVE) L.pcand[pos] = k;
+      ncand += __popcll(mk);
+    }
+    if (ncand > WAVE) { ncand = WAVE; over = true; }
+    __syncthreads();
+    for (int ci = 0; ci < ncand; ci++) {
+      const int k = L.pcand[ci];
+      const int a = m.pair_a[k], b = m.pair_b[k];
+      T depth, dir[3], pos[3];
+      if (!mpr_penetration(m, L, lane, a, b, depth, dir, pos)) continue;
+      if (ncon - nfl >= MAXHH || ncon >= MAXCON) { over = true; continue; }
+      if (lane == 0) {
+        L.cbody[ncon] = b;
+        L.cvert[ncon] = 0x8000 | a;
+        L.cdist[ncon] = -depth;
+        L.hb1[ncon - nfl] = a;
+#pragma unroll
+        for (int i = 0; i < 3; i++) { L.cr[ncon][i] = pos[i]; L.hn[ncon - nfl][i] = dir[i]; }
+      }
+      if (!((bodyanc_of(m, b) >> a) & 1u) && !((bodyanc_of(m, a) >> b) & 1u)) hh_cross = true;
+      ncon++;
+    }
+    if (over) fail |= 8;
+  }
   __syncthreads();
   if (lane == 0 && ncon_out) ncon_out[0] = ncon;
   if (con_out && lane < MAXCON) con_out[lane] = lane < ncon ? ((L.cbody[lane] << 16) | L.cvert[lane]) : -1;
 
   TSIDB_STAMP(19);
   // ---- constraint rows: frictionloss (lane = dof), pyramidal contact rows (lane = contact)
-  const T mu = envp ? envp[1] : m.contact[0];
+  // friction: floor contacts take the per-env value (config 5), robot<->robot contacts the model's
+  const T mu = (lane >= nfl || !envp) ? m.contact[0] : envp[1];
   const T timeconst = m.contact[1] > 2 * dt ? m.contact[1] : 2 * dt, dampratio = m.contact[2];
   const T dmin = m.contact[3], dmax = m.contact[4], width = m.contact[5], mid = m.contact[6], power = m.contact[7];
   const T kk = T(1) / (dmax * dmax * timeconst * timeconst * dampratio * dampratio), bb = T(2) / (dmax * timeconst);
@@ -513,13 +924,14 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
       else y = 1 - pow(1 - x, power) / pow(1 - mid, power - 1);
       imp = dmin + y * (dmax - dmin);
     }
-    const T tran = m.mj_body_invw0[L.cbody[c]][0];
+    T tran = m.mj_body_invw0[L.cbody[c]][0];
+    if (c >= nfl) tran += m.mj_body_invw0[L.hb1[c - nfl]][0]; // geom1's body (the floor contributes 0)
     const T diagA = tran + mu * mu * tran;
     T R0 = (1 - imp) / imp * diagA;
     R0 = R0 > MINVAL ? R0 : MINVAL;
     rs.cD = T(1) / (2 * mu * mu * R0);
     T vel[4];
-    contact_rows(m, L, fl, c, L.qvel, mu, vel);
+    contact_rows(m, L, nfl, c, L.qvel, mu, vel);
 #pragma unroll
     for (int i = 0; i < 4; i++) rs.caref[i] = -bb * vel[i] - kk * imp * (dist - margin);
   }
@@ -534,7 +946,7 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
       if (rs.has_f) rs.fjar = xa - rs.faref;
       if (rs.has_c) {
         T o[4];
-        contact_rows(m, L, fl, lane, L.xv, mu, o);
+        contact_rows(m, L, nfl, lane, L.xv, mu, o);
 #pragma unroll
         for (int i = 0; i < 4; i++) rs.cjar[i] = o[i] - rs.caref[i];
       }
@@ -591,14 +1003,16 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
       if (rs.has_c) {
         T fr[4];
         T fv[3] = {0, 0, 0};
+        T cn[3], ct1[3], ct2[3];
+        contact_frame(L, lane, nfl, cn, ct1, ct2);
 #pragma unroll
         for (int i = 0; i < 4; i++) {
           const bool act = rs.cjar[i] < 0;
           fr[i] = act ? -rs.cD * rs.cjar[i] : T(0);
           // direction of row i in world axes: n + s*mu*t_k
           const T sg = (i & 1) ? -mu : mu;
-          const T *tk = i < 2 ? fl.t1 : fl.t2;
-          const T dir[3] = {fl.n[0] + sg * tk[0], fl.n[1] + sg * tk[1], fl.n[2] + sg * tk[2]};
+          const T *tk = i < 2 ? ct1 : ct2;
+          const T dir[3] = {cn[0] + sg * tk[0], cn[1] + sg * tk[1], cn[2] + sg * tk[2]};
 #pragma unroll
           for (int e = 0; e < 3; e++) fv[e] += fr[i] * dir[e];
           if (act) {
@@ -615,11 +1029,15 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
         const int k = lane, bk = k < 6 ? 0 : k - 5;
         T s = 0;
         for (int c = 0; c < ncon; c++) {
-          if (!((L.anc[L.cbody[c]] >> bk) & 1u)) continue;
+          // +1 on geom2's chain, -1 on geom1's, 0 above their common ancestor
+          int sgn = (int)((L.anc[L.cbody[c]] >> bk) & 1u);
+          if (c >= nfl) sgn -= (int)((L.anc[L.hb1[c - nfl]] >> bk) & 1u);
+          if (sgn == 0) continue;
           T rxf[3];
           cross3(L.cr[c], L.cfv[c], rxf);
-          s += L.S[k][0] * L.cfv[c][0] + L.S[k][1] * L.cfv[c][1] + L.S[k][2] * L.cfv[c][2] +
-               L.S[k][3] * rxf[0] + L.S[k][4] * rxf[1] + L.S[k][5] * rxf[2];
+          const T js = L.S[k][0] * L.cfv[c][0] + L.S[k][1] * L.cfv[c][1] + L.S[k][2] * L.cfv[c][2] +
+                       L.S[k][3] * rxf[0] + L.S[k][4] * rxf[1] + L.S[k][5] * rxf[2];
+          s += sgn > 0 ? js : -js;
         }
         grad = Ma - qfs - s - ff;
       }
@@ -662,10 +1080,10 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
       unsigned touched = 0;
       {
         T accK = 0;
-        for (int c = 0; c < ncon; c++) {
+        for (int c = 0; c < nfl; c++) { // floor contacts; the robot<->robot ones are added below as rank-3 terms
           const int b = L.cbody[c];
           if (lane < 21) accK += L.Wc[c][lane];
-          if (c + 1 == ncon || L.cbody[c + 1] != b) {
+          if (c + 1 == nfl || L.cbody[c + 1] != b) {
             const unsigned am = L.anc[b];
             for (unsigned mk = am; mk; mk &= mk - 1) {
               const int a = __ffs(mk) - 1;
@@ -707,15 +1125,38 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
       TSIDB_LAP(25);
 #pragma unroll
       for (int j = 0; j < NV; j++) arow[j] = lane < NV ? L.H[lane * LDM + j] : T(0);
+      // robot<->robot contacts: H += J^T A J with J = the contact point's relative velocity per unit dof rate
+      // (3 x 26, column k on lane k) and A = sum over the active rows of D dir dir^T (3 x 3, held by the
+      // contact's lane): lane i adds j_i . (A j_k) to its row for every k
+      for (int c = nfl; c < ncon; c++) {
+        T A6[6];
+#pragma unroll
+        for (int e = 0; e < 6; e++) A6[e] = rdlane_dyn(Arow[e], c);
+        T jk[3] = {0, 0, 0};
+        if (lane < NV) {
+          const int bk = lane < 6 ? 0 : lane - 5;
+          const int sgn = (int)((L.anc[L.cbody[c]] >> bk) & 1u) - (int)((L.anc[L.hb1[c - nfl]] >> bk) & 1u);
+          if (sgn != 0) {
+            T wxr[3];
+            cross3(&L.S[lane][3], L.cr[c], wxr);
+#pragma unroll
+            for (int i = 0; i < 3; i++) jk[i] = sgn > 0 ? L.S[lane][i] + wxr[i] : -(L.S[lane][i] + wxr[i]);
+          }
+        }
+        const T g[3] = {A6[0] * jk[0] + A6[1] * jk[1] + A6[2] * jk[2], A6[1] * jk[0] + A6[3] * jk[1] + A6[4] * jk[2],
+                        A6[2] * jk[0] + A6[4] * jk[1] + A6[5] * jk[2]};
+#pragma unroll
+        for (int k = 0; k < NV; k++) arow[k] += jk[0] * rdlane(g[0], k) + jk[1] * rdlane(g[1], k) + jk[2] * rdlane(g[2], k);
+      }
       bool ok;
-      const T search = -chol26_solve(arow, grad, lane, ok);
+      const T search = -(hh_cross ? chol26_solve<T, true>(arow, grad, lane, ok) : chol26_solve<T, false>(arow, grad, lane, ok));
       if (!ok) { fail |= 2; break; }
       TSIDB_LAP(26);
       // ---- exact line search along `search`
       stage(search);
       const T Mv = mulM(L, L.xv, lane);
       if (rs.has_f) rs.fJv = search;
-      if (rs.has_c) contact_rows(m, L, fl, lane, L.xv, mu, rs.cJv);
+      if (rs.has_c) contact_rows(m, L, nfl, lane, L.xv, mu, rs.cJv);
       T qg1 = wave_sum(lane < NV ? search * (Ma - qfs) : T(0));
       T qg2 = wave_sum(lane < NV ? T(0.5) * search * Mv : T(0));
       T snorm = sqrt(wave_sum(lane < NV ? search * search : T(0)));

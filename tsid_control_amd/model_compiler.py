@@ -206,6 +206,19 @@ def load_stl_vertices(path: Path):
     return np.unique(d["v"].reshape(-1, 3).astype(np.float64), axis=0)
 
 
+def hull_volume_centroid(verts):
+    """Centre of mass of the solid convex hull (what MuJoCo re-centres a mesh geom on, so what its convex
+    collision functions use as the geom centre): volume-weighted mean of the tetrahedra (o, a, b, c) over the
+    hull's triangles, o = an interior point."""
+    from scipy.spatial import ConvexHull
+
+    h = ConvexHull(verts)
+    o = verts[h.vertices].mean(0)
+    a, b, c = (verts[h.simplices[:, k]] - o for k in range(3))
+    vol = np.abs(np.einsum("ij,ij->i", a, np.cross(b, c))) / 6.0
+    return o + ((a + b + c) / 4.0 * vol[:, None]).sum(0) / vol.sum()
+
+
 def convex_hull_graph(verts):
     """Hull vertices + neighbour lists (edges of the triangulated hull, as qhull 'Qt' gives MuJoCo)."""
     from scipy.spatial import ConvexHull
@@ -291,7 +304,7 @@ def build_sim_model(mjcf_robot: Path, mesh_dir: Path):
     actuators = [p.get("joint") for p in root.find("actuator").findall("position")]
 
     hull_v, hull_adr, edge_adr, edges, rb = [], [0], [0], [], []
-    chunk_adr, chunk_box = [0], []
+    chunk_adr, chunk_box, hull_center, hull_box = [0], [], [], []
     for b in bodies:
         v = load_stl_vertices(mesh_dir / mesh_file[b["mesh"]])
         hv, eadr, e = convex_hull_graph(v)
@@ -314,6 +327,8 @@ def build_sim_model(mjcf_robot: Path, mesh_dir: Path):
         assert chunk_adr[-1] - chunk_adr[-2] <= 64, "a hull may have at most 64 chunks (4096 vertices)"
         c = 0.5 * (hv_body.min(0) + hv_body.max(0))
         rb.append(np.concatenate([c, [np.linalg.norm(hv_body - c, axis=1).max()]]))
+        hull_center.append(hull_volume_centroid(hv_body))
+        hull_box.append(np.concatenate([c, 0.5 * (hv_body.max(0) - hv_body.min(0))]))
         hull_v.append(hv_body)
         edge_adr.extend((eadr[1:] + len(edges)).tolist())
         edges.extend(e.tolist())
@@ -324,6 +339,7 @@ def build_sim_model(mjcf_robot: Path, mesh_dir: Path):
         hull_v=np.concatenate(hull_v), hull_adr=np.array(hull_adr, np.int32),
         edge_adr=np.array(edge_adr, np.int32), edges=np.array(edges, np.int32), rbound=np.array(rb),
         chunk_adr=np.array(chunk_adr, np.int32), chunk_box=np.array(chunk_box),
+        hull_center=np.array(hull_center), hull_box=np.array(hull_box),
     )
 
 
@@ -456,6 +472,7 @@ def compile_model(ref_root: Path, out: Path):
         "mj_hull_eadr": sim["edge_adr"], "mj_hull_edge": sim["edges"],
         "mj_rbound": sim["rbound"], "mj_pairs": np.array(pairs, np.int32),
         "mj_chunk_adr": sim["chunk_adr"], "mj_chunk_box": sim["chunk_box"],
+        "mj_hull_center": sim["hull_center"], "mj_hull_box": sim["hull_box"],
         # MuJoCo option / contact defaults (no <option>, no geom contact attrs in the MJCF)
         "mj_opt": np.array([0.002, -9.81, 1e-8, 100, 50, 0.01, 1.0]),  # dt gz tol iters ls_iters ls_tol impratio
         "mj_contact": np.array([1.0, 0.02, 1.0, 0.9, 0.95, 0.001, 0.5, 2.0]),  # mu, solref[2], solimp[5]

@@ -77,6 +77,7 @@ class WalkController:
         self.ncon, self.con_pairs = z(N, dt=torch.int32), z(N, MAXCON, dt=torch.int32)
         self.info = z(N, 4, dt=torch.int32)
         self.env_params = None
+        self.terrain = None
         rc = L.tsidb_set_refs(self._h, _ptr(self.com_ref), _ptr(self.posture_ref), _ptr(self.foot_ref),
                               _ptr(self.contact_ref), _ptr(self.contact_active), _ptr(self.cop_frames))
         _lib.check(L, self._h, rc, "tsidb_set_refs")
@@ -117,16 +118,17 @@ class WalkController:
         rc = self._L.tsidb_set_params(self._h, self.params.ctypes.data_as(C.c_void_p), P_COUNT)
         _lib.check(self._L, self._h, rc, "tsidb_set_params")
 
-    def set_env_params(self, mass_scale=None, friction=None, floor_normal=None, floor_offset=None):
+    def set_env_params(self, mass_scale=None, friction=None, floor_normal=None, floor_offset=None, terrain=None):
         """Per-env randomisation of the sim stage (BASELINE config 5; no reference counterpart): any
-        of mass_scale [N], friction [N], floor_normal [N,3] (normalised here), floor_offset [N].
-        Calling with no argument restores the nominal model."""
+        of mass_scale [N], friction [N] (floor contacts), floor_normal [N,3] (normalised here), floor_offset [N],
+        terrain = dict(direction [N,2], phase [N], step_length [N] or float, heights [N,16]): a stepped floor -
+        the surface is raised along its normal by heights[cell & 15], cell = floor((direction . x_world_xy - phase)
+        / step_length).  Calling with no argument restores the nominal model."""
         self.sync_sim()  # a sim stage left in flight by step_pipelined() may still read the old table
+        N = self.num_envs
         if mass_scale is None and friction is None and floor_normal is None and floor_offset is None:
             self.env_params = None
-            rc = self._L.tsidb_set_env_params(self._h, None)
         else:
-            N = self.num_envs
             ep = torch.zeros(N, 8, dtype=self.dtype, device=self.device)
             ep[:, 0], ep[:, 1], ep[:, 4] = 1.0, 1.0, 1.0
             if mass_scale is not None:
@@ -139,19 +141,43 @@ class WalkController:
             if floor_offset is not None:
                 ep[:, 5] = torch.as_tensor(floor_offset, dtype=self.dtype, device=self.device)
             self.env_params = ep
-            rc = self._L.tsidb_set_env_params(self._h, _ptr(ep))
+        if terrain is None:
+            self.terrain = None
+        else:
+            tr = torch.zeros(N, 20, dtype=torch.float64)
+            d = torch.as_tensor(terrain["direction"], dtype=torch.float64).reshape(N, 2)
+            tr[:, 0:2] = d / d.norm(dim=1, keepdim=True)
+            tr[:, 2] = torch.as_tensor(terrain.get("phase", 0.0), dtype=torch.float64)
+            tr[:, 3] = 1.0 / torch.as_tensor(terrain["step_length"], dtype=torch.float64)
+            tr[:, 4:] = torch.as_tensor(terrain["heights"], dtype=torch.float64).reshape(N, 16)
+            self.terrain = tr.to(self.device, self.dtype).contiguous()
+        rc = self._L.tsidb_set_env_params(self._h, _ptr(self.env_params), _ptr(self.terrain))
         _lib.check(self._L, self._h, rc, "tsidb_set_env_params")
 
-    def randomize(self, seed=2, mass=(0.8, 1.2), friction=(0.4, 1.0), tilt_deg=5.0):
+    def randomize(self, seed=2, mass=(0.8, 1.2), friction=(0.4, 1.0), tilt_deg=5.0, step_height=0.01, step_length=(0.04, 0.12)):
         """BASELINE config 5 workload: body-mass scale U(mass), contact friction
-        U(friction), floor = random plane through the origin tilted by at most tilt_deg."""
+        U(friction), floor = random plane through the origin tilted by at most tilt_deg, with terrain steps of
+        step_height (1 cm): strips of width U(step_length) across a random horizontal direction, each strip raised
+        by 0 or step_height at random (period 16 strips; the strip under the robot's start is level).
+        step_height = 0 leaves the floor a plane."""
         g = torch.Generator().manual_seed(seed)
         N = self.num_envs
         u = lambda lo, hi: lo + (hi - lo) * torch.rand(N, generator=g, dtype=torch.float64)
         tilt = torch.deg2rad(u(0.0, tilt_deg))
         az = u(0.0, 2 * np.pi)
         nrm = torch.stack([torch.sin(tilt) * torch.cos(az), torch.sin(tilt) * torch.sin(az), torch.cos(tilt)], dim=1)
-        self.set_env_params(mass_scale=u(*mass), friction=u(*friction), floor_normal=nrm, floor_offset=torch.zeros(N, dtype=torch.float64))
+        terrain = None
+        if step_height > 0:
+            ang = u(0.0, 2 * np.pi)
+            length = u(*step_length)
+            heights = step_height * torch.randint(0, 2, (N, 16), generator=g).to(torch.float64)
+            heights[:, 0] = 0.0
+            heights[:, 15] = 0.0
+            # cell 0 is centred on the world origin (where every env's robot starts): phase = -length / 2
+            terrain = dict(direction=torch.stack([torch.cos(ang), torch.sin(ang)], dim=1), phase=-0.5 * length,
+                           step_length=length, heights=heights)
+        self.set_env_params(mass_scale=u(*mass), friction=u(*friction), floor_normal=nrm,
+                            floor_offset=torch.zeros(N, dtype=torch.float64), terrain=terrain)
 
     # ------------------------------------------------------------------ reset / step
     def reset(self, env_ids=None):
