@@ -172,7 +172,7 @@ class Oracle:
         return dict(tau=tau, dv=dv, f=f, obs=obs, status=st, iters=it.value)
 
     # ---- sim
-    def sim_step(self, qpos, qvel, ctrl, qacc_ws, envp=None, terrain=None, self_collision=False):
+    def sim_step(self, qpos, qvel, ctrl, qacc_ws, envp=None, terrain=None, self_collision=True):
         assert all(x.dtype == np.float64 for x in (qpos, qvel, qacc_ws))
         ctrl = _f64(ctrl)
         info = OrSimInfo()

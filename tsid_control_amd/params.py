@@ -83,7 +83,7 @@ def pack_params(conf, effort_limit, velocity_limit):
     p[P_REW_CTAU] = getattr(conf, "reward_torque_cost", 1e-3)
     p[P_DONE_HEIGHT] = getattr(conf, "done_base_height", 0.2)
     p[P_DONE_TILT] = np.cos(np.deg2rad(getattr(conf, "done_tilt_deg", 45.0)))
-    p[P_SELF_COLLISION] = 1.0 if getattr(conf, "self_collision", False) else 0.0
+    p[P_SELF_COLLISION] = 1.0 if getattr(conf, "self_collision", True) else 0.0
     p[P_W_COP] = getattr(conf, "w_cop", 0.0)
     if p[P_CLOSED_LOOP] and not p[P_SIM_ENABLED]:
         raise ValueError("closed_loop needs the sim stage (sim_enabled=True)")
