@@ -39,7 +39,8 @@ struct SimLds {
     };
     struct {            // collision-time scratch, overlays K only
       T terr[20];       // stepped-terrain table of this env
-      int pcand[64];    // candidate pairs that passed the mid phase
+      int pcand[64];    // candidate pairs that passed the bounding-sphere test / the mid phase
+      T scen[NB][4];    // bounding spheres in the world (relative to O): centre, radius
     };
   };
   T M[NV * LDM];
@@ -491,15 +492,15 @@ __device__ __forceinline__ bool mpr_penetration(const DevModel<T> &m, const SimL
 // mid phase for one candidate pair (one lane per pair): bounding spheres, then the 15-axis separating-axis test
 // on the hulls' body-frame boxes
 template <typename T>
-__device__ __forceinline__ bool pair_may_touch(const DevModel<T> &m, const SimLds<T> &L, int a, int b) {
+__device__ __forceinline__ bool spheres_overlap(const SimLds<T> &L, int a, int b) {
+  const T d[3] = {L.scen[a][0] - L.scen[b][0], L.scen[a][1] - L.scen[b][1], L.scen[a][2] - L.scen[b][2]};
+  const T rr = L.scen[a][3] + L.scen[b][3];
+  return !(dot3(d, d) > rr * rr);
+}
+template <typename T>
+__device__ __forceinline__ bool boxes_may_touch(const DevModel<T> &m, const SimLds<T> &L, int a, int b) {
   const T *Ra = L.R[a], *Rb = L.R[b];
   T ca[3], cb[3], d[3];
-  mat3vec(Ra, m.rbound[a], ca);
-  mat3vec(Rb, m.rbound[b], cb);
-#pragma unroll
-  for (int i = 0; i < 3; i++) d[i] = (ca[i] + L.p[a][i]) - (cb[i] + L.p[b][i]);
-  const T rr = m.rbound[a][3] + m.rbound[b][3];
-  if (dot3(d, d) > rr * rr) return false;
   mat3vec(Ra, m.hbox[a], ca);
   mat3vec(Rb, m.hbox[b], cb);
 #pragma unroll
@@ -779,7 +780,11 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
   const T margin = 0, tie_tol = m.opt[6];
   const T Ow[3] = {L.qpos[0], L.qpos[1], L.qpos[2]};
   const T nO = dot3(fl.n, Ow) - fl.d; // signed distance of the base origin O to the floor plane
+#ifdef TSIDB_NO_TERR
+  const bool has_terr = false;
+#else
   const bool has_terr = terr_g != nullptr;
+#endif
   T hmax_all = 0;
   if (has_terr) { // the tree-pass scratch is dead: stage this env's terrain table over it
     if (lane < 20) L.terr[lane] = terr_g[lane];
@@ -850,20 +855,39 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
   // ---- collision: robot<->robot convex-hull pairs (robot.xml:13-15 after the excludes of :18-52 and the
   //      parent-child filter): mid phase one lane per pair, narrow phase (MPR) one pair at a time on the wave
   bool hh_cross = false; // some robot<->robot contact couples two branches of the tree (dense Newton Hessian)
+#ifndef TSIDB_NO_HH
   if (m.params[P_SELF_COLLISION] != 0) {
-    __syncthreads(); // the terrain table is dead; pcand overlays it
-    int ncand = 0;
+    // bounding spheres of all bodies in the world (lane = body, whose placement is still in its registers)
+    if (lane < NB) {
+      T c[3];
+      mat3vec(Rb, m.rbound[lane], c);
+      L.scen[lane][0] = c[0] + pb[0]; L.scen[lane][1] = c[1] + pb[1]; L.scen[lane][2] = c[2] + pb[2];
+      L.scen[lane][3] = m.rbound[lane][3];
+    }
+    __syncthreads();
+    // broad phase, one lane per pair: sphere test, survivors compacted; then the box test once on the survivors
+    int nsph = 0;
     bool over = false;
     for (int k0 = 0; k0 < m.npair; k0 += WAVE) {
       const int k = k0 + lane;
-      bool may = false;
-      if (k < m.npair) may = pair_may_touch(m, L, m.pair_a[k], m.pair_b[k]);
+      const bool may = k < m.npair && spheres_overlap(L, m.pair_a[k], m.pair_b[k]);
       const unsigned long long mk = __ballot(may);
-      const int pos = ncand + __popcll(mk & ((1ull << lane) - 1ull));
+      const int pos = nsph + __popcll(mk & ((1ull << lane) - 1ull));
       if (may && pos < WAVE) L.pcand[pos] = k;
-      ncand += __popcll(mk);
+      nsph += __popcll(mk);
     }
-    if (ncand > WAVE) { ncand = WAVE; over = true; }
+    if (nsph > WAVE) { nsph = WAVE; over = true; }
+    __syncthreads();
+    int ncand = 0;
+    {
+      const int k = lane < nsph ? L.pcand[lane] : 0;
+      const bool may = lane < nsph && boxes_may_touch(m, L, m.pair_a[k], m.pair_b[k]);
+      const unsigned long long mk = __ballot(may);
+      const int pos = __popcll(mk & ((1ull << lane) - 1ull));
+      __syncthreads();
+      if (may) L.pcand[pos] = k; // in pair order: ballot positions preserve it
+      ncand = __popcll(mk);
+    }
     __syncthreads();
     for (int ci = 0; ci < ncand; ci++) {
       const int k = L.pcand[ci];
@@ -884,6 +908,7 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
     }
     if (over) fail |= 8;
   }
+#endif
   __syncthreads();
   if (lane == 0 && ncon_out) ncon_out[0] = ncon;
   if (con_out && lane < MAXCON) con_out[lane] = lane < ncon ? ((L.cbody[lane] << 16) | L.cvert[lane]) : -1;
@@ -1122,12 +1147,10 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
       }
       if (fact) L.H[lane * LDM + lane] += rs.fD;
       __syncthreads();
-      TSIDB_LAP(25);
-#pragma unroll
-      for (int j = 0; j < NV; j++) arow[j] = lane < NV ? L.H[lane * LDM + j] : T(0);
-      // robot<->robot contacts: H += J^T A J with J = the contact point's relative velocity per unit dof rate
-      // (3 x 26, column k on lane k) and A = sum over the active rows of D dir dir^T (3 x 3, held by the
-      // contact's lane): lane i adds j_i . (A j_k) to its row for every k
+      // robot<->robot contacts (rare): H += J^T A J with J = the contact point's relative velocity per unit dof
+      // rate (3 x 26, column k on lane k) and A = sum over the active rows of D dir dir^T (3 x 3, held by the
+      // contact's lane).  Done on the LDS copy of H, before its rows go to registers: g_k = A j_k is staged in the
+      // (now dead) composite-inertia scratch, then lane i adds j_i . g_k to its row for every k.
       for (int c = nfl; c < ncon; c++) {
         T A6[6];
 #pragma unroll
@@ -1142,12 +1165,21 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
 #pragma unroll
             for (int i = 0; i < 3; i++) jk[i] = sgn > 0 ? L.S[lane][i] + wxr[i] : -(L.S[lane][i] + wxr[i]);
           }
+          T *g = &L.K[0][0] + 3 * lane;
+          g[0] = A6[0] * jk[0] + A6[1] * jk[1] + A6[2] * jk[2];
+          g[1] = A6[1] * jk[0] + A6[3] * jk[1] + A6[4] * jk[2];
+          g[2] = A6[2] * jk[0] + A6[4] * jk[1] + A6[5] * jk[2];
         }
-        const T g[3] = {A6[0] * jk[0] + A6[1] * jk[1] + A6[2] * jk[2], A6[1] * jk[0] + A6[3] * jk[1] + A6[4] * jk[2],
-                        A6[2] * jk[0] + A6[4] * jk[1] + A6[5] * jk[2]};
-#pragma unroll
-        for (int k = 0; k < NV; k++) arow[k] += jk[0] * rdlane(g[0], k) + jk[1] * rdlane(g[1], k) + jk[2] * rdlane(g[2], k);
+        __syncthreads();
+        if (lane < NV) {
+          const T *g = &L.K[0][0];
+          for (int k = 0; k < NV; k++) L.H[lane * LDM + k] += jk[0] * g[3 * k] + jk[1] * g[3 * k + 1] + jk[2] * g[3 * k + 2];
+        }
+        __syncthreads();
       }
+      TSIDB_LAP(25);
+#pragma unroll
+      for (int j = 0; j < NV; j++) arow[j] = lane < NV ? L.H[lane * LDM + j] : T(0);
       bool ok;
       const T search = -(hh_cross ? chol26_solve<T, true>(arow, grad, lane, ok) : chol26_solve<T, false>(arow, grad, lane, ok));
       if (!ok) { fail |= 2; break; }
