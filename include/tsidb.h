@@ -63,6 +63,10 @@ int tsidb_set_params(tsidb_handle h, const double *params, int n_params);
 int tsidb_set_refs(tsidb_handle h, const void *com_ref, const void *posture_ref, const void *foot_ref,
                    const void *contact_ref, const uint8_t *contact_active, const void *cop_frames);
 
+/* reference point of the CoP force task (legacy/biped.py:79-80 copTask; params[W_COP] != 0): cop_ref [N,3], world
+ * frame; written by tsidb_reset (midpoint of the soles on the floor).  The pointer is remembered, not copied. */
+int tsidb_set_cop_ref(tsidb_handle h, const void *cop_ref);
+
 /* per-env randomisation of the sim stage (BASELINE.json configs[4]; no reference counterpart):
  * env_params [N,8] in the path's arithmetic type = mass scale applied to every sim body's mass and inertia,
  * contact friction, unit floor normal (3), floor offset d (plane n.x = d), 2 spare.  NULL = nominal

@@ -36,7 +36,7 @@ int or_env_step_batch_env(const OrModel *m, const double *params, int n, double 
                           int32_t *status, double *obs, int32_t *ncon, int32_t *con_geom, int nthreads) {
   return or_env_step_batch_walk(m, params, n, q, v, qpos, qvel, qacc_ws, (double *)com_ref, posture_ref, (double *)foot_ref,
                                 (double *)contact_ref, (uint8_t *)contact_active, cop_frames, env_params, tau, dv, f, status, obs,
-                                ncon, con_geom, nthreads, NULL, NULL, NULL, NULL);
+                                ncon, con_geom, nthreads, NULL, NULL, NULL, NULL, NULL);
 }
 
 /* the same env step preceded, per env, by the walking reference update of or_walk.c when `w` is given (the
@@ -47,7 +47,7 @@ int or_env_step_batch_walk(const OrModel *m, const double *params, int n, double
                            double *foot_ref, double *contact_ref, uint8_t *contact_active,
                            const double *cop_frames, const double *env_params, double *tau, double *dv, double *f,
                            int32_t *status, double *obs, int32_t *ncon, int32_t *con_geom, int nthreads,
-                           const OrWalkTables *w, double *frames, double *rewdone, const double *terrain) {
+                           const OrWalkTables *w, double *frames, double *rewdone, const double *terrain, const double *cop_ref) {
   const int sim = params[P_SIM_ENABLED] != 0.0;
   const int closed = params[P_CLOSED_LOOP] != 0.0;
   const int quirks = params[P_QUIRKS] != 0.0 && !closed;
@@ -64,10 +64,11 @@ int or_env_step_batch_walk(const OrModel *m, const double *params, int n, double
                      foot_ref + (size_t)e * 48, contact_ref + (size_t)e * 24, contact_active + (size_t)e * 2,
                      com_ref + (size_t)e * 9);
     if (closed) sim_to_tsid(m, qpos + (size_t)e * OR_NQ, qvel + (size_t)e * OR_NV, qe, ve);
-    int st = or_tsid_tick(m, params, qe, ve, com_ref + (size_t)e * 9, posture_ref + (size_t)e * OR_NA,
-                          foot_ref + (size_t)e * 48, contact_ref + (size_t)e * 24, contact_active + (size_t)e * 2,
-                          cop_frames ? cop_frames + (size_t)e * 24 : NULL, tau + (size_t)e * OR_NA,
-                          dv + (size_t)e * OR_NV, f + (size_t)e * 24, obs ? obs + (size_t)e * OR_NOBS : NULL, NULL);
+    int st = or_tsid_tick_cop(m, params, qe, ve, com_ref + (size_t)e * 9, posture_ref + (size_t)e * OR_NA,
+                              foot_ref + (size_t)e * 48, contact_ref + (size_t)e * 24, contact_active + (size_t)e * 2,
+                              cop_frames ? cop_frames + (size_t)e * 24 : NULL, cop_ref ? cop_ref + (size_t)e * 3 : NULL,
+                              tau + (size_t)e * OR_NA, dv + (size_t)e * OR_NV, f + (size_t)e * 24,
+                              obs ? obs + (size_t)e * OR_NOBS : NULL, NULL);
     status[e] = st;
     if (frames && st != 4) memcpy(frames + (size_t)e * 24, or_last_frames, sizeof or_last_frames);
     if (rewdone) { rewdone[2 * (size_t)e] = or_last_rowx[0]; rewdone[2 * (size_t)e + 1] = or_last_rowx[1]; }

@@ -91,6 +91,15 @@ void or_tsid_assemble(const OrModel *m, const double *params, const OrTerms *t, 
                       const double *v, const double *com_ref, const double *posture_ref,
                       const double *foot_ref, const double *contact_ref, const uint8_t *contact_active,
                       OrQP *qp) {
+  or_tsid_assemble_cop(m, params, t, q, v, com_ref, posture_ref, foot_ref, contact_ref, contact_active, NULL, qp);
+}
+
+/* cop_ref (may be NULL): reference point of the CoP force task (legacy/biped.py:79-80, tsid::TaskCopEquality), used
+ * when params[P_W_COP] != 0 */
+void or_tsid_assemble_cop(const OrModel *m, const double *params, const OrTerms *t, const double *q,
+                          const double *v, const double *com_ref, const double *posture_ref,
+                          const double *foot_ref, const double *contact_ref, const uint8_t *contact_active,
+                          const double *cop_ref, OrQP *qp) {
   (void)m;
   memset(qp, 0, sizeof *qp);
   int nslot = 0;
@@ -182,6 +191,31 @@ void or_tsid_assemble(const OrModel *m, const double *params, const OrTerms *t, 
     for (int r = 0; r < 6; r++) for (int c = 0; c < 12; c++) A[r][OR_NV + 12 * s + c] = wreg[r] * T[r][c];
     ACCUM(6, params[P_W_FORCEREF]);
     (void)f;
+  }
+  if (params[P_W_COP] != 0.0 && cop_ref && nslot > 0) {
+    /* CoP force task: the tangential moment of the contact forces about the reference point vanishes,
+     * [n]x sum_c sum_i (p_c + R_c r_i - p_ref) x (R_c f_ci) = 0 - three rows (rank 2) over all force variables,
+     * as a level-1 cost with weight w_cop (addForceTask(copTask, w_cop, 1), legacy/biped.py:80) */
+    memset(A, 0, sizeof A); memset(a, 0, sizeof a);
+    const double *nn = params + P_NORMAL;
+    for (int s = 0; s < nslot; s++) {
+      const int f = qp->slot_foot[s];
+      const double *R = t->oMf[f], *pc = t->oMf[f] + 9;
+      for (int i = 0; i < 4; i++) {
+        const double *r = params + P_CPOINTS + 3 * i;
+        double d[3];
+        for (int k2 = 0; k2 < 3; k2++) d[k2] = pc[k2] + R[3 * k2] * r[0] + R[3 * k2 + 1] * r[1] + R[3 * k2 + 2] * r[2] - cop_ref[k2];
+        for (int j = 0; j < 3; j++) { /* unit force along local axis j of the contact frame */
+          const double fw[3] = {R[j], R[3 + j], R[6 + j]};
+          const double mo[3] = {d[1] * fw[2] - d[2] * fw[1], d[2] * fw[0] - d[0] * fw[2], d[0] * fw[1] - d[1] * fw[0]};
+          const int col = OR_NV + 12 * s + 3 * i + j;
+          A[0][col] = nn[1] * mo[2] - nn[2] * mo[1];
+          A[1][col] = nn[2] * mo[0] - nn[0] * mo[2];
+          A[2][col] = nn[0] * mo[1] - nn[1] * mo[0];
+        }
+      }
+    }
+    ACCUM(3, params[P_W_COP]);
   }
   for (int f = 0; f < OR_NF; f++) { /* foot SE3 tasks (always in the stack) */
     memset(A, 0, sizeof A);
@@ -474,6 +508,14 @@ int or_tsid_tick(const OrModel *m, const double *params, double *q, double *v, c
                  const double *posture_ref, const double *foot_ref, const double *contact_ref,
                  const uint8_t *contact_active, const double *cop_frames, double *tau, double *dv,
                  double *f, double *obs, int *iters) {
+  return or_tsid_tick_cop(m, params, q, v, com_ref, posture_ref, foot_ref, contact_ref, contact_active, cop_frames, NULL, tau,
+                          dv, f, obs, iters);
+}
+
+int or_tsid_tick_cop(const OrModel *m, const double *params, double *q, double *v, const double *com_ref,
+                     const double *posture_ref, const double *foot_ref, const double *contact_ref,
+                     const uint8_t *contact_active, const double *cop_frames, const double *cop_ref, double *tau,
+                     double *dv, double *f, double *obs, int *iters) {
   static __thread OrTerms t;
   static __thread OrQP qp;
   static __thread OrQPSol sol;
@@ -493,7 +535,7 @@ int or_tsid_tick(const OrModel *m, const double *params, double *q, double *v, c
   }
   or_rbd_terms(m, q, v, &t);
   memcpy(or_last_frames, t.oMf, sizeof or_last_frames);
-  or_tsid_assemble(m, params, &t, q, v, com_ref, posture_ref, foot_ref, contact_ref, contact_active, &qp);
+  or_tsid_assemble_cop(m, params, &t, q, v, com_ref, posture_ref, foot_ref, contact_ref, contact_active, cop_ref, &qp);
   int status = or_qp_solve(&qp, (int)params[P_MAX_ITER], &sol);
   if (iters) *iters = sol.iter;
   memset(f, 0, 24 * sizeof(double));

@@ -104,6 +104,10 @@ void or_tsid_assemble(const OrModel *m, const double *params, const OrTerms *t, 
                       const double *v, const double *com_ref, const double *posture_ref,
                       const double *foot_ref, const double *contact_ref, const uint8_t *contact_active,
                       OrQP *qp);
+void or_tsid_assemble_cop(const OrModel *m, const double *params, const OrTerms *t, const double *q,
+                          const double *v, const double *com_ref, const double *posture_ref,
+                          const double *foot_ref, const double *contact_ref, const uint8_t *contact_active,
+                          const double *cop_ref /* [3] or NULL: CoP task reference (params[P_W_COP]) */, OrQP *qp);
 int or_qp_solve(const OrQP *qp, int max_iter, OrQPSol *sol); /* eiquadprog-fast restatement */
 
 /* one TSID tick for one env: main.py:119-129,132-142 */
@@ -111,6 +115,11 @@ int or_tsid_tick(const OrModel *m, const double *params, double *q, double *v, c
                  const double *posture_ref, const double *foot_ref, const double *contact_ref,
                  const uint8_t *contact_active, const double *cop_frames /*2x12, quirk (e)*/,
                  double *tau, double *dv, double *f, double *obs, int *iters);
+
+int or_tsid_tick_cop(const OrModel *m, const double *params, double *q, double *v, const double *com_ref,
+                     const double *posture_ref, const double *foot_ref, const double *contact_ref,
+                     const uint8_t *contact_active, const double *cop_frames, const double *cop_ref, double *tau,
+                     double *dv, double *f, double *obs, int *iters);
 
 /* MuJoCo-subset step for one env: main.py:195 */
 typedef struct {
@@ -175,7 +184,8 @@ int or_env_step_batch_walk(const OrModel *m, const double *params, int n, double
                            int32_t *status, double *obs, int32_t *ncon, int32_t *con_geom, int nthreads,
                            const OrWalkTables *w /* NULL: references as given */, double *frames /* [n,2,12] or NULL */,
                            double *rewdone /* [n,2] reward, done; or NULL */,
-                           const double *terrain /* [n,20] stepped-terrain tables (or_collide.c) or NULL */);
+                           const double *terrain /* [n,20] stepped-terrain tables (or_collide.c) or NULL */,
+                           const double *cop_ref /* [n,3] CoP task reference or NULL */);
 
 #ifdef __cplusplus
 }

@@ -138,13 +138,15 @@ class Oracle:
         return out
 
     # ---- TSID problem
-    def assemble(self, params, q, v, com_ref, posture_ref, foot_ref, contact_ref, contact_active):
+    def assemble(self, params, q, v, com_ref, posture_ref, foot_ref, contact_ref, contact_active, cop_ref=None):
         t = self.terms(q, v)["_raw"]
         qp = OrQP()
         a = [_f64(x) for x in (params, q, v, com_ref, posture_ref, foot_ref, contact_ref)]
         ca = np.ascontiguousarray(contact_active, dtype=np.uint8)
-        self.lib.or_tsid_assemble(self.m, _p(a[0]), C.byref(t), _p(a[1]), _p(a[2]), _p(a[3]), _p(a[4]), _p(a[5]),
-                                  _p(a[6]), _p(ca), C.byref(qp))
+        cr = _f64(cop_ref) if cop_ref is not None else None
+        self.lib.or_tsid_assemble_cop.restype = None
+        self.lib.or_tsid_assemble_cop(self.m, _p(a[0]), C.byref(t), _p(a[1]), _p(a[2]), _p(a[3]), _p(a[4]), _p(a[5]),
+                                      _p(a[6]), _p(ca), _p(cr) if cr is not None else None, C.byref(qp))
         n, ne, ni = qp.nvar, qp.neq, qp.nin
         H = np.array(qp.H).reshape(NVAR, NVAR)[:n, :n]
         CE = np.array(qp.CE).reshape(NEQ, NVAR)[:ne, :n]
@@ -159,7 +161,7 @@ class Oracle:
         return dict(status=st, x=np.array(sol.x)[:n], u=np.array(sol.u)[:sol.iq], A=np.array(sol.A)[:sol.iq],
                     iq=sol.iq, iter=sol.iter, f_value=sol.f_value)
 
-    def tsid_tick(self, params, q, v, com_ref, posture_ref, foot_ref, contact_ref, contact_active, cop_frames=None):
+    def tsid_tick(self, params, q, v, com_ref, posture_ref, foot_ref, contact_ref, contact_active, cop_frames=None, cop_ref=None):
         """In-place on q, v (float64 arrays). Returns dict(tau, dv, f, obs, status, iters)."""
         assert q.dtype == np.float64 and v.dtype == np.float64
         a = [_f64(x) for x in (params, com_ref, posture_ref, foot_ref, contact_ref)]
@@ -167,8 +169,11 @@ class Oracle:
         cf = _f64(cop_frames) if cop_frames is not None else None
         tau, dv, f, obs = np.zeros(NA), np.zeros(NV), np.zeros(24), np.zeros(NOBS)
         it = C.c_int(0)
-        st = self.lib.or_tsid_tick(self.m, _p(a[0]), _p(q), _p(v), _p(a[1]), _p(a[2]), _p(a[3]), _p(a[4]), _p(ca),
-                                   _p(cf) if cf is not None else None, _p(tau), _p(dv), _p(f), _p(obs), C.byref(it))
+        cr = _f64(cop_ref) if cop_ref is not None else None
+        self.lib.or_tsid_tick_cop.restype = C.c_int
+        st = self.lib.or_tsid_tick_cop(self.m, _p(a[0]), _p(q), _p(v), _p(a[1]), _p(a[2]), _p(a[3]), _p(a[4]), _p(ca),
+                                       _p(cf) if cf is not None else None, _p(cr) if cr is not None else None,
+                                       _p(tau), _p(dv), _p(f), _p(obs), C.byref(it))
         return dict(tau=tau, dv=dv, f=f, obs=obs, status=st, iters=it.value)
 
     # ---- sim
@@ -211,6 +216,7 @@ class Oracle:
         fr = st.get("frames")
         rd = st.get("rewdone")
         tr = st.get("terrain")
+        cr = st.get("cop_ref")
         if walk is not None and fr is None:
             raise ValueError("walking env step needs st['frames']")
         self.lib.or_env_step_batch_walk(
@@ -220,7 +226,8 @@ class Oracle:
             _p(st["tau"]), _p(st["dv"]), _p(st["f"]),
             _p(st["status"]), _p(st["obs"]), _p(st["ncon"]), _p(st["con_geom"]), int(nthreads),
             C.byref(walk.c) if walk is not None else None, _p(fr) if fr is not None else None,
-            _p(rd) if rd is not None else None, _p(tr) if tr is not None else None)
+            _p(rd) if rd is not None else None, _p(tr) if tr is not None else None,
+            _p(cr) if cr is not None else None)
 
 
 def walk_update(lib, sched, t, frames, foot_ref, contact_ref, contact_active, com_ref):

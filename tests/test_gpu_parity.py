@@ -854,3 +854,85 @@ def test_fallen_robot_with_self_collision(oracle):
             both += int((r["con_body1"] >= 0).any() and (r["con_body1"] < 0).any())
         assert diff(wc.qpos, qpos) < 1e-7 and diff(wc.qvel, qvel) < 1e-4, i
     assert both > 20 and bool(torch.isfinite(wc.qpos).all())
+
+
+def test_config5_full_size_properties():
+    """BASELINE configs[4] at its full size - 65 536 envs with per-env mass / friction / floor tilt / 1 cm terrain
+    steps - through size-independent properties: nothing fails or is flagged, states stay finite and unit-norm, the
+    contact lists are well formed, and a slice re-run on its own
+    controller is bit-identical (what the sharded run relies on)."""
+    n = 65536
+    wc = make(n)
+    perturb(wc, 19, dq=0.03, dv=0.03)
+    wc.randomize(seed=2)
+    q0, v0 = wc.q.clone(), wc.v.clone()
+    for _ in range(30):
+        wc.step()
+    assert int((wc.status != 0).sum()) == 0 and int((wc.info[:, 3] != 0).sum()) == 0
+    for t in (wc.q, wc.v, wc.qpos, wc.qvel, wc.tau, wc.rows):
+        assert bool(torch.isfinite(t).all())
+    assert float((wc.qpos[:, 3:7].norm(dim=1) - 1).abs().max()) < 1e-12
+    nc = wc.ncon
+    # (the sim's base is teleported to the TSID pose every step, main.py:192: on a floor tilted away under it a robot
+    # hovers - most envs touch, none exceeds the cap)
+    assert int(nc.min()) >= 0 and int(nc.max()) <= 32 and float((nc > 0).float().mean()) > 0.5
+    cp = wc.con_pairs
+    valid = torch.arange(32, device=wc.device)[None, :] < nc[:, None]
+    assert bool((cp[~valid] == -1).all()) and bool((cp[valid] >= 0).all())
+    body, vert = cp >> 16, cp & 0xffff
+    assert bool((body[valid] < 21).all()) and bool(((vert[valid] < 2823) | (vert[valid] >= 0x8000)).all())
+    assert int(wc.done.sum()) == 0 and float(wc.reward.min()) > 0
+    # a slice stepped on its own controller with the same per-env parameters: bit-identical
+    lo, hi = 40000, 40512
+    sub = make(hi - lo)
+    sub.q.copy_(q0[lo:hi]); sub.v.copy_(v0[lo:hi])
+    sub.env_params = wc.env_params[lo:hi].clone()
+    sub.terrain = wc.terrain[lo:hi].clone()
+    rc = sub._L.tsidb_set_env_params(sub._h, sub.env_params.data_ptr(), sub.terrain.data_ptr())
+    assert rc == 0
+    for _ in range(30):
+        sub.step()
+    for name in ("q", "v", "qpos", "qvel", "tau", "rows", "ncon", "con_pairs"):
+        assert torch.equal(getattr(sub, name), getattr(wc, name)[lo:hi]), name
+
+
+def test_cop_force_task_f64(oracle):
+    """SURVEY 8f-3's last piece: the legacy controller's CoP force task (legacy/biped.py:79-80) as a rank-2 term on the
+    force block of the Hessian (the k_tick<T, COP=true> variant); light and heavy weights, double and single
+    support, moving states, references off the support centre."""
+    for w_cop in (1e-2, 50.0):
+        n = 48
+        wc = make(n, sim_enabled=False, w_cop=w_cop)
+        perturb(wc, 43, dq=0.1, dv=0.5)
+        wc.contact_active[::3, 0] = 0
+        wc.contact_active[1::5, 1] = 0
+        wc.contact_active[(wc.contact_active.sum(dim=1) == 0), 1] = 1
+        g = torch.Generator().manual_seed(3)
+        wc.cop_ref[:, :2] += ((torch.rand(n, 2, generator=g, dtype=torch.float64) - 0.5) * 0.04).to(wc.device)
+        st = mirror(wc)
+        cr = wc.cop_ref.cpu().numpy()
+        wc.tick()
+        for e in range(n):
+            out = oracle.tsid_tick(wc.params, st["q"][e], st["v"][e], st["com_ref"][e], st["posture_ref"][e], st["foot_ref"][e],
+                                   st["contact_ref"][e], st["contact_active"][e], st["cop_frames"][e], cop_ref=cr[e])
+            st["tau"][e], st["dv"][e], st["f"][e], st["status"][e] = out["tau"], out["dv"], out["f"], out["status"]
+        assert np.array_equal(wc.status.cpu().numpy(), st["status"])
+        ok = st["status"] == 0
+        assert ok.sum() > n // 2
+        assert np.allclose(wc.dv.cpu().numpy()[ok], st["dv"][ok], rtol=1e-7, atol=1e-7)
+        assert np.allclose(wc.tau.cpu().numpy()[ok], st["tau"][ok], rtol=1e-7, atol=1e-7)
+        assert np.abs(wrench(wc.f.cpu().numpy(), wc.params)[ok] - wrench(st["f"], wc.params)[ok]).max() < 1e-6
+        assert diff(wc.q[ok], st["q"][ok]) < 1e-9
+    # the task does something: the same states without it give different contact forces
+    ref = make(n, sim_enabled=False)
+    perturb(ref, 43, dq=0.1, dv=0.5)
+    ref.contact_active.copy_(wc.contact_active)
+    ref.tick()
+    assert float((ref.f - wc.f).abs().max()) > 1e-2
+    # reset writes the CoP reference between the soles, on the floor
+    fresh = make(3, w_cop=1.0)
+    mid = 0.5 * (fresh.frames[:, 0, 9:11] + fresh.frames[:, 1, 9:11])
+    assert float((fresh.cop_ref[:, :2] - mid).abs().max()) < 1e-15 and float(fresh.cop_ref[:, 2].abs().max()) == 0
+    for _ in range(20):
+        fresh.step()
+    assert int((fresh.status != 0).sum()) == 0

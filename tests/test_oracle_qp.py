@@ -225,3 +225,57 @@ def test_scipy_cross_check_with_active_inequalities(oracle, params, standing):
         assert np.abs(r.x[:NV] - sol["x"][:NV]).max() < 2e-2 * max(1.0, np.abs(sol["x"][:NV]).max())
         checked += 1
     assert checked >= 3
+
+
+def test_cop_task_enters_the_cost(oracle, params, standing, blob):
+    """the legacy controller's CoP force task (legacy/biped.py:79-80, tsid TaskCopEquality ++): with
+    w_cop != 0 the force block of the Hessian gains w_cop A^T A, A = the tangential moment of the contact forces
+    about the reference point - built here independently from its definition; a heavy weight moves the centre of
+    pressure of the solved forces onto the reference."""
+    from tsid_control_amd.conf import RobotConfig
+    from tsid_control_amd.params import P_CPOINTS, P_W_COP, pack_params
+    conf = RobotConfig()
+    conf.w_cop = 1e-2
+    p_cop = pack_params(conf, blob.effort_limit, blob.velocity_limit)
+    assert p_cop[P_W_COP] == 1e-2
+    rng = np.random.default_rng(21)
+    q = standing["q"].copy()
+    q[7:] += rng.uniform(-0.05, 0.05, 20)
+    v = rng.normal(0, 0.2, NV)
+    t = oracle.terms(q, v)
+    cop_ref = 0.5 * (t["oMf"][0][9:] + t["oMf"][1][9:]) + np.array([0.01, -0.015, 0.0])
+    cop_ref[2] = 0.0
+
+    def moment_rows(active):
+        cols = []
+        for f in (0, 1):
+            if not active[f]:
+                continue
+            R, pc = t["oMf"][f][:9].reshape(3, 3), t["oMf"][f][9:]
+            for i in range(4):
+                d = pc + R @ params[P_CPOINTS + 3 * i:P_CPOINTS + 3 * i + 3] - cop_ref
+                for j in range(3):
+                    cols.append(np.cross([0, 0, 1.0], np.cross(d, R[:, j])))
+        return np.array(cols).T                                                  # 3 x (12 nslot)
+
+    for active in ((1, 1), (1, 0), (0, 1)):
+        a = oracle.assemble(params, q, v, standing["com_ref"], standing["posture_ref"], standing["foot_ref"],
+                            standing["contact_ref"], np.array(active, np.uint8))
+        b = oracle.assemble(p_cop, q, v, standing["com_ref"], standing["posture_ref"], standing["foot_ref"],
+                            standing["contact_ref"], np.array(active, np.uint8), cop_ref=cop_ref)
+        A = moment_rows(active)
+        dH = b["H"] - a["H"]
+        assert np.abs(dH[26:, 26:] - 1e-2 * A.T @ A).max() < 1e-13 and np.abs(dH[:26]).max() == 0
+        assert np.abs(b["g"] - a["g"]).max() == 0                                # zero reference: no linear term
+    # heavy weight, double support: the CoP of the solved forces sits on the reference
+    conf.w_cop = 1e3
+    p_hv = pack_params(conf, blob.effort_limit, blob.velocity_limit)
+    c = oracle.assemble(p_hv, q, v, standing["com_ref"], standing["posture_ref"], standing["foot_ref"],
+                        standing["contact_ref"], np.array((1, 1), np.uint8), cop_ref=cop_ref)
+    a = oracle.assemble(params, q, v, standing["com_ref"], standing["posture_ref"], standing["foot_ref"],
+                        standing["contact_ref"], np.array((1, 1), np.uint8))
+    sa, sc = oracle.qp_solve(a["_raw"]), oracle.qp_solve(c["_raw"])
+    assert sa["status"] == 0 and sc["status"] == 0
+    kkt_check(c, sc, tol=1e-5)
+    A = moment_rows((1, 1))
+    assert np.linalg.norm(A @ sc["x"][26:]) < 0.05 * np.linalg.norm(A @ sa["x"][26:])

@@ -10,7 +10,7 @@ import os
 LIB_PATH = Path(os.environ.get("TSIDB_LIB_PATH", _HERE / "libtsidb.so"))
 
 SYMBOLS = ["tsidb_create", "tsidb_destroy", "tsidb_last_error", "tsidb_set_params", "tsidb_set_refs", "tsidb_reset",
-           "tsidb_tick", "tsidb_sim", "tsidb_step", "tsidb_rbd_terms", "tsidb_lds_bytes", "tsidb_walk_update", "tsidb_set_env_params"]
+           "tsidb_tick", "tsidb_sim", "tsidb_step", "tsidb_rbd_terms", "tsidb_lds_bytes", "tsidb_walk_update", "tsidb_set_env_params", "tsidb_set_cop_ref"]
 
 _lib = None
 
@@ -42,6 +42,7 @@ def load():
     L.tsidb_rbd_terms.argtypes = [vp] * 10
     L.tsidb_lds_bytes.argtypes = [C.c_int, C.c_int]
     L.tsidb_set_env_params.argtypes = [vp, vp, vp]
+    L.tsidb_set_cop_ref.argtypes = [vp, vp]
     L.tsidb_walk_update.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int] + [C.c_double] * 6 + [vp, vp, vp]
     for s in SYMBOLS:
         if s != "tsidb_last_error":

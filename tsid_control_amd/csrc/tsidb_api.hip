@@ -20,12 +20,14 @@ using namespace tsidb;
 // a variant with nothing to do still queues 4096 workgroups that each need the full LDS allocation, and
 // in one stream it holds the working variant back behind whatever else occupies the GPU (the sim of
 // the previous step): 11.0 M -> 12.9 M env-steps/s from merging them.
-template <typename T>
+// COP: the variant with the CoP force task rows (legacy/biped.py:79-80) compiled in; the reference's
+// ctrl/WalkController.py stack (w_cop = 0) runs the variant without them.
+template <typename T, bool COP>
 __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2))) void k_tick(const DevModel<T> *__restrict__ mp, int n, T *q, T *v, const T *com_ref,
                                                   const T *posture_ref, const T *foot_ref, const T *contact_ref,
                                                   const uint8_t *cact, const T *cop_frames, T *tau, T *dv, T *f,
                                                   int *status, T *obs, int obs_ld, T *frames, int *info, const T *qpos_sim,
-                                                  const T *qvel_sim) {
+                                                  const T *qvel_sim, const T *cop_ref) {
   __shared__ TickLds<T> L;
   const int e = blockIdx.x, lane = threadIdx.x;
   if (e >= n) return;
@@ -52,20 +54,20 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2))) void 
     }
   }
   if (ns == 2) {
-    tsid_tick_env<T, 2>(*mp, L, lane, q + E * NQ, v + E * NV, com_ref + E * 9, posture_ref + E * NA, foot_ref + E * 48,
+    tsid_tick_env<T, 2, COP>(*mp, L, lane, q + E * NQ, v + E * NV, com_ref + E * 9, posture_ref + E * NA, foot_ref + E * 48,
                          contact_ref + E * 24, cact + E * 2, cop_frames ? cop_frames + E * 24 : nullptr, tau + E * NA,
                          dv + E * NV, f + E * 24, status + e, obs ? obs + E * obs_ld : nullptr, (obs && obs_ld >= NROW) ? obs + E * obs_ld + NOBS : nullptr, info ? info + E * 4 : nullptr,
-                         qpos_sim ? qpos_sim + E * NQ : nullptr, qvel_sim ? qvel_sim + E * NV : nullptr);
+                         qpos_sim ? qpos_sim + E * NQ : nullptr, qvel_sim ? qvel_sim + E * NV : nullptr, cop_ref ? cop_ref + E * 3 : nullptr);
   } else if (ns == 1) {
-    tsid_tick_env<T, 1>(*mp, L, lane, q + E * NQ, v + E * NV, com_ref + E * 9, posture_ref + E * NA, foot_ref + E * 48,
+    tsid_tick_env<T, 1, COP>(*mp, L, lane, q + E * NQ, v + E * NV, com_ref + E * 9, posture_ref + E * NA, foot_ref + E * 48,
                          contact_ref + E * 24, cact + E * 2, cop_frames ? cop_frames + E * 24 : nullptr, tau + E * NA,
                          dv + E * NV, f + E * 24, status + e, obs ? obs + E * obs_ld : nullptr, (obs && obs_ld >= NROW) ? obs + E * obs_ld + NOBS : nullptr, info ? info + E * 4 : nullptr,
-                         qpos_sim ? qpos_sim + E * NQ : nullptr, qvel_sim ? qvel_sim + E * NV : nullptr);
+                         qpos_sim ? qpos_sim + E * NQ : nullptr, qvel_sim ? qvel_sim + E * NV : nullptr, cop_ref ? cop_ref + E * 3 : nullptr);
   } else {
-    tsid_tick_env<T, 0>(*mp, L, lane, q + E * NQ, v + E * NV, com_ref + E * 9, posture_ref + E * NA, foot_ref + E * 48,
+    tsid_tick_env<T, 0, COP>(*mp, L, lane, q + E * NQ, v + E * NV, com_ref + E * 9, posture_ref + E * NA, foot_ref + E * 48,
                          contact_ref + E * 24, cact + E * 2, cop_frames ? cop_frames + E * 24 : nullptr, tau + E * NA,
                          dv + E * NV, f + E * 24, status + e, obs ? obs + E * obs_ld : nullptr, (obs && obs_ld >= NROW) ? obs + E * obs_ld + NOBS : nullptr, info ? info + E * 4 : nullptr,
-                         qpos_sim ? qpos_sim + E * NQ : nullptr, qvel_sim ? qvel_sim + E * NV : nullptr);
+                         qpos_sim ? qpos_sim + E * NQ : nullptr, qvel_sim ? qvel_sim + E * NV : nullptr, cop_ref ? cop_ref + E * 3 : nullptr);
   }
   if (frames && lane < 24) frames[E * 24 + lane] = L.oMf[lane / 12][lane % 12];
 }
@@ -122,7 +124,7 @@ __global__ __launch_bounds__(WAVE) void k_rbd(const DevModel<T> *__restrict__ mp
 template <typename T>
 __global__ __launch_bounds__(WAVE) void k_reset(const DevModel<T> *__restrict__ mp, int n, const int *env_ids, int n_ids, T *q,
                                                 T *v, T *qpos, T *qvel, T *qacc_ws, T *com_ref, T *posture_ref,
-                                                T *foot_ref, T *contact_ref, uint8_t *cact, T *cop_frames) {
+                                                T *foot_ref, T *contact_ref, uint8_t *cact, T *cop_frames, T *cop_ref) {
   __shared__ TickLds<T> L;
   const DevModel<T> &m = *mp;
   const int lane = threadIdx.x;
@@ -168,6 +170,8 @@ __global__ __launch_bounds__(WAVE) void k_reset(const DevModel<T> *__restrict__ 
   if (lane < 9) com_ref[E * 9 + lane] = lane < 3 ? L.com[lane] : T(0);
   if (lane < NA) posture_ref[E * NA + lane] = L.qs[7 + lane];
   if (lane < 2) cact[E * 2 + lane] = 1;
+  // CoP task reference: between the soles, on the floor
+  if (cop_ref && lane < 3) cop_ref[E * 3 + lane] = lane < 2 ? T(0.5) * (L.oMf[0][9 + lane] + L.oMf[1][9 + lane]) : T(0);
 }
 
 // walking reference update: one lane per env (Walk_Planner.py:23-31 samples -> WalkController.py:189-253)
@@ -365,7 +369,7 @@ struct tsidb_ctx {
   int *d_eadr = nullptr, *d_edge = nullptr;
   const void *com_ref = nullptr, *posture_ref = nullptr, *foot_ref = nullptr, *contact_ref = nullptr, *cop_frames = nullptr;
   const uint8_t *contact_active = nullptr;
-  const void *env_params = nullptr, *terrain = nullptr;
+  const void *env_params = nullptr, *terrain = nullptr, *cop_ref = nullptr;
   std::string err;
 };
 
@@ -426,6 +430,7 @@ static void build_model(tsidb_ctx *h, DevModel<T> &m) {
         m.Bcone[16][3 * i + k] = (T)n[k];
       }
     for (int i = 0; i < 16; i++) { m.cone_lb[i] = (T)-1e10; m.cone_ub[i] = 0; }
+    for (int k = 0; k < 3; k++) { m.cop_t[0][k] = (T)t1[k]; m.cop_t[1][k] = (T)t2[k]; }
     m.cone_lb[16] = (T)P[P_FMIN];
     m.cone_ub[16] = (T)P[P_FMAX];
   }
@@ -575,6 +580,7 @@ extern "C" int tsidb_set_env_params(tsidb_handle h, const void *env_params, cons
 
 static void need_refs(tsidb_ctx *h) {
   if (!h->com_ref) throw std::string("reference buffers not registered (call tsidb_set_refs first)");
+  if (h->params[P_W_COP] != 0.0 && !h->cop_ref) throw std::string("w_cop != 0 needs a CoP reference (tsidb_set_cop_ref)");
 }
 
 template <typename T>
@@ -582,12 +588,13 @@ static void launch_tick(tsidb_ctx *h, void *q, void *v, void *tau, void *dv, voi
                         void *frames, int32_t *info, hipStream_t s, const void *qpos_sim = nullptr,
                         const void *qvel_sim = nullptr) {
   if (obs && obs_ld < NOBS) throw std::string("obs row stride must be at least TSIDB_NOBS");
-#define TSIDB_LAUNCH_TICK(NS)                                                                                              \
-  hipLaunchKernelGGL((k_tick<T>), dim3(h->num_envs), dim3(WAVE), 0, s, (const DevModel<T> *)h->d_model, h->num_envs,   \
+#define TSIDB_LAUNCH_TICK(COP)                                                                                             \
+  hipLaunchKernelGGL((k_tick<T, COP>), dim3(h->num_envs), dim3(WAVE), 0, s, (const DevModel<T> *)h->d_model, h->num_envs,   \
                      (T *)q, (T *)v, (const T *)h->com_ref, (const T *)h->posture_ref, (const T *)h->foot_ref,             \
                      (const T *)h->contact_ref, h->contact_active, (const T *)h->cop_frames, (T *)tau, (T *)dv, (T *)f,    \
-                     status, (T *)obs, obs_ld, (T *)frames, info, (const T *)qpos_sim, (const T *)qvel_sim)
-  TSIDB_LAUNCH_TICK(2);
+                     status, (T *)obs, obs_ld, (T *)frames, info, (const T *)qpos_sim, (const T *)qvel_sim, (const T *)h->cop_ref)
+  if (h->params[P_W_COP] != 0.0) TSIDB_LAUNCH_TICK(true);
+  else TSIDB_LAUNCH_TICK(false);
 #undef TSIDB_LAUNCH_TICK
   HIP_OK(hipGetLastError());
 }
@@ -661,6 +668,12 @@ int tsidb_set_refs(tsidb_handle h, const void *com_ref, const void *posture_ref,
   return 0;
 }
 
+int tsidb_set_cop_ref(tsidb_handle h, const void *cop_ref) {
+  if (!h) return -1;
+  h->cop_ref = cop_ref;
+  return 0;
+}
+
 int tsidb_reset(tsidb_handle h, const int32_t *env_ids, int n_ids, void *q, void *v, void *qpos, void *qvel,
                 void *qacc_ws, void *stream) {
   GUARD_BEGIN
@@ -673,12 +686,12 @@ int tsidb_reset(tsidb_handle h, const int32_t *env_ids, int n_ids, void *q, void
     hipLaunchKernelGGL(k_reset<double>, dim3(grid), dim3(WAVE), 0, s, (const DevModel<double> *)h->d_model, h->num_envs,
                        env_ids, n_ids, (double *)q, (double *)v, (double *)qpos, (double *)qvel, (double *)qacc_ws,
                        (double *)h->com_ref, (double *)h->posture_ref, (double *)h->foot_ref, (double *)h->contact_ref,
-                       (uint8_t *)h->contact_active, (double *)h->cop_frames);
+                       (uint8_t *)h->contact_active, (double *)h->cop_frames, (double *)h->cop_ref);
   else
     hipLaunchKernelGGL(k_reset<float>, dim3(grid), dim3(WAVE), 0, s, (const DevModel<float> *)h->d_model, h->num_envs,
                        env_ids, n_ids, (float *)q, (float *)v, (float *)qpos, (float *)qvel, (float *)qacc_ws,
                        (float *)h->com_ref, (float *)h->posture_ref, (float *)h->foot_ref, (float *)h->contact_ref,
-                       (uint8_t *)h->contact_active, (float *)h->cop_frames);
+                       (uint8_t *)h->contact_active, (float *)h->cop_frames, (float *)h->cop_ref);
   HIP_OK(hipGetLastError());
   GUARD_END
 }

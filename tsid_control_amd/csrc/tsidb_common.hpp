@@ -70,6 +70,7 @@ struct DevModel {
   T cone_lb[17], cone_ub[17];
   T Jf0[12][12];   // L_f^-T of the (constant) force-regularisation Hessian block
   T Hf_trace, Jf0_trace;
+  T cop_t[2][3];   // tangents of the contact normal (CoP task rows)
   // ---- sim side
   int mj_parent[NB], mj_depth[NB], mj_nchild[NB], mj_child[NB][MAXCHILD];
   unsigned mj_anc[NB];

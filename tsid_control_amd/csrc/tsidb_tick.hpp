@@ -724,9 +724,9 @@ __device__ __forceinline__ int qp_active_regs(const DevModel<T> &m, TickLds<T> &
 // QP of one contact configuration (NS = number of feet in contact: variables 26 + 12 NS, equalities
 // 6 + 6 NS) from the Cholesky factor of the dv block onwards; sized at compile time so that the
 // register-resident rows/columns and every unrolled loop carry no padding for absent contacts.
-template <typename T, int NS>
+template <typename T, int NS, bool COP>
 __device__ __forceinline__ void tick_qp(const DevModel<T> &m, TickLds<T> &L, QpCtx<T> &c, int lane, const T (&a)[NV],
-                                        const T (&rd)[NV], T gi, T c1, bool spd, int &qp_status, int &qp_iters) {
+                                        const T (&rd)[NV], T gi, T c1, bool spd, const T *cop_ref, int &qp_status, int &qp_iters) {
   // ---- three forward substitutions with L share its broadcast entries:
   //   y  = L^-1 (-g)                      (uniform, lane i contributes y_i)
   //   xr = L^-1 e_lane                    (column `lane` of L^-1 = row `lane` of J0 = L^-T)
@@ -799,6 +799,76 @@ __device__ __forceinline__ void tick_qp(const DevModel<T> &m, TickLds<T> &L, QpC
           for (int b = 0; b <= e; b++) sacc += m.Jf0[b][e] * ce[b];
           bc[NV + 12 * s2 + e] = sacc;
         }
+      }
+    }
+    if constexpr (NS > 0 && COP) {
+      const T w_cop = m.params[P_W_COP];
+      if (w_cop != 0 && cop_ref) {
+        // CoP force task (legacy/biped.py:79-80, tsid TaskCopEquality): cost w |t x sum_i (x_i - p_ref) x f_i|^2 over the
+        // two tangents t of the contact normal, x_i the world position of contact point i, f_i its force - the
+        // tangential moment of the contact forces about the reference CoP.  Its Hessian w A^T A (A: 2 x 12 NS) is a
+        // rank-2 term on top of the constant force-regularisation block L0 L0^T, so the factor J with J J^T = H_f^-1
+        // is J0 (I - b1 a1 a1^T)(I - b2 b b^T) with a_k = rows of A J0: two rank-1 corrections of the constant rows.
+        const int col = lane - NV; // force variable of this lane
+        const bool isf = lane >= NV && lane < n;
+        const T tiny = sizeof(T) == 8 ? T(1e-30) : T(1e-20);
+        T A0 = 0, A1 = 0;
+        if (isf) {
+          const int sl = col / 12, pt = (col % 12) / 3, j = col % 3, f = c.slot_foot[sl];
+          const T *R = L.oMf[f], *pp = L.oMf[f] + 9;
+          const T *r = &m.params[P_CPOINTS + 3 * pt];
+          T d[3], x1[3], x2[3];
+#pragma unroll
+          for (int i = 0; i < 3; i++) d[i] = pp[i] + R[3 * i] * r[0] + R[3 * i + 1] * r[1] + R[3 * i + 2] * r[2] - cop_ref[i];
+          cross3(m.cop_t[0], d, x1);
+          cross3(m.cop_t[1], d, x2);
+          A0 = R[j] * x1[0] + R[3 + j] * x1[1] + R[6 + j] * x1[2]; // component j of R^T (t x d)
+          A1 = R[j] * x2[0] + R[3 + j] * x2[1] + R[6 + j] * x2[2];
+        }
+        __syncthreads();
+        if (isf) { L.x[col] = A0; L.x[24 + col] = A1; }
+        __syncthreads();
+        T t0 = 0, t1 = 0; // this lane's column of A J0 (J0 upper triangular within each foot's block)
+        if (isf) {
+          const int sl = col / 12, cb = col % 12;
+          for (int a2 = 0; a2 <= cb; a2++) {
+            const T jf = m.Jf0[a2][cb];
+            t0 += L.x[12 * sl + a2] * jf;
+            t1 += L.x[24 + 12 * sl + a2] * jf;
+          }
+        }
+        const T al1 = wave_sum(t0 * t0), a12 = wave_sum(t0 * t1);
+        const T be1 = al1 > tiny ? (1 - T(1) / sqrt(1 + w_cop * al1)) / al1 : T(0);
+        const T bq = t1 - be1 * a12 * t0;
+        const T al2 = wave_sum(bq * bq);
+        const T be2 = al2 > tiny ? (1 - T(1) / sqrt(1 + w_cop * al2)) / al2 : T(0);
+        __syncthreads();
+        if (isf) { L.x[col] = t0; L.x[24 + col] = bq; }
+        __syncthreads();
+        if (isf) { // row of J: j0 (I - b1 a1 a1^T)(I - b2 b b^T)
+          T s1 = 0, s2 = 0;
+#pragma unroll
+          for (int cc = 0; cc < 12 * NS; cc++) s1 += jr[NV + cc] * L.x[cc];
+#pragma unroll
+          for (int cc = 0; cc < 12 * NS; cc++) jr[NV + cc] -= be1 * s1 * L.x[cc];
+#pragma unroll
+          for (int cc = 0; cc < 12 * NS; cc++) s2 += jr[NV + cc] * L.x[24 + cc];
+#pragma unroll
+          for (int cc = 0; cc < 12 * NS; cc++) jr[NV + cc] -= be2 * s2 * L.x[24 + cc];
+        }
+        if (lane < 6) { // column of B = J^T CE^T: the same two (symmetric) factors, in the same order
+          T s1 = 0, s2 = 0;
+#pragma unroll
+          for (int cc = 0; cc < 12 * NS; cc++) s1 += bc[NV + cc] * L.x[cc];
+#pragma unroll
+          for (int cc = 0; cc < 12 * NS; cc++) bc[NV + cc] -= be1 * s1 * L.x[cc];
+#pragma unroll
+          for (int cc = 0; cc < 12 * NS; cc++) s2 += bc[NV + cc] * L.x[24 + cc];
+#pragma unroll
+          for (int cc = 0; cc < 12 * NS; cc++) bc[NV + cc] -= be2 * s2 * L.x[24 + cc];
+        }
+        c1 += w_cop * wave_sum(A0 * A0 + A1 * A1); // trace of the Hessian (tolerance scale only)
+        __syncthreads();
       }
     }
     TSIDB_STAMP(5);
@@ -892,11 +962,11 @@ __device__ __forceinline__ void tick_qp(const DevModel<T> &m, TickLds<T> &L, QpC
 }
 
 // --------------------------------------------------------------------------- the tick
-template <typename T, int NS>
+template <typename T, int NS, bool COP>
 __device__ __forceinline__ void tsid_tick_env(const DevModel<T> &m, TickLds<T> &L, int lane, T *q, T *v, const T *com_ref,
                               const T *posture_ref, const T *foot_ref, const T *contact_ref,
                               const uint8_t *cact, const T *cop_frames, T *tau, T *dv, T *fout, int *status_out,
-                              T *obs, T *rowx, int *info, const T *qpos_sim, const T *qvel_sim) {
+                              T *obs, T *rowx, int *info, const T *qpos_sim, const T *qvel_sim, const T *cop_ref) {
   TSIDB_STAMP(0);
   // ---- stage state.  Closed loop: the TSID state is read from the sim state each
   //      tick - quat wxyz -> xyzw, world-frame base linear velocity -> body frame, sim joint order ->
@@ -1029,7 +1099,7 @@ __device__ __forceinline__ void tsid_tick_env(const DevModel<T> &m, TickLds<T> &
     for (int j = k + 1; j < NV; j++) a[j] -= lik * rdlane(lik, j);
   }
   TSIDB_STAMP(4);
-  tick_qp<T, NS>(m, L, c, lane, a, rd, gi, c1, spd, qp_status, qp_iters);
+  tick_qp<T, NS, COP>(m, L, c, lane, a, rd, gi, c1, spd, cop_ref, qp_status, qp_iters);
   int status = qp_status, iters = qp_iters;
 
   TSIDB_STAMP(8);

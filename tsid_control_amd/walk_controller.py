@@ -81,6 +81,8 @@ class WalkController:
         rc = L.tsidb_set_refs(self._h, _ptr(self.com_ref), _ptr(self.posture_ref), _ptr(self.foot_ref),
                               _ptr(self.contact_ref), _ptr(self.contact_active), _ptr(self.cop_frames))
         _lib.check(L, self._h, rc, "tsidb_set_refs")
+        self.cop_ref = z(N, 3)   # reference of the CoP force task (legacy/biped.py:79-80; conf.w_cop)
+        _lib.check(L, self._h, L.tsidb_set_cop_ref(self._h, _ptr(self.cop_ref)), "tsidb_set_cop_ref")
 
         # WalkController.py:168-169,179-180
         self.tau_max = conf.tau_max_scaling * self.model.effort_limit
