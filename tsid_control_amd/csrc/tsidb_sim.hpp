@@ -69,13 +69,20 @@ __device__ __forceinline__ int sym_idx(int i, int j) { // packed upper index of 
 // only ancestor pairs are touched; MJ_DOFANC is a compile-time table, so the unrolled code simply
 // does not contain the zero updates.  U[i][k] ends up in lane i's a[k] (k >= i).
 // DENSE: a robot<->robot contact between two branches of the tree couples dofs that are not ancestor-related;
-// the same elimination order then runs over all pairs.
+// the same elimination then runs over all pairs, in index order.
+// Two variations were measured and dropped (round 2, 4096 walkers, k_sim back to back 0.238 ms): pivots in an
+// interleaved order (children before parents, branches alternating, so that consecutive pivots are independent):
+// 0.242 ms - the routine is VALU-issue bound, not latency bound; broadcasts through LDS (each pivot's column written
+// once, ancestors' entries read back at uniform addresses: one LDS instruction instead of the two v_readlane a
+// float64 broadcast costs): 0.260 ms - the values then sit in VGPRs the kernel does not have (86 spilled) and the
+// per-pivot LDS round trip is exposed.
 template <typename T, bool DENSE>
 __device__ __forceinline__ T chol26_solve(T (&a)[NV], T rhs, int lane, bool &spd) {
   spd = true;
   T rd[NV]; // 1 / U[k][k], wave-uniform
 #pragma unroll
-  for (int k = NV - 1; k >= 0; k--) {
+  for (int t = 0; t < NV; t++) {
+    const int k = NV - 1 - t;
     const T akk = rdlane(a[k], k);
     if (!(akk > 0)) spd = false;
     const T rk = rsqrt_t(akk > 0 ? akk : T(1));
@@ -86,16 +93,18 @@ __device__ __forceinline__ T chol26_solve(T (&a)[NV], T rhs, int lane, bool &spd
     for (int j = 0; j < k; j++)
       if (DENSE || ((MJ_DOFANC[k] >> j) & 1u)) a[j] -= uik * rdlane(uik, j);
   }
-  // U y = rhs (k descending; lane k contributes y_k), then U^T x = y (k ascending, wave-uniform)
+  // U y = rhs (descendants first; lane k contributes y_k), then U^T x = y (ancestors first, wave-uniform)
   T acc = rhs, y[NV];
 #pragma unroll
-  for (int k = NV - 1; k >= 0; k--) {
+  for (int t = 0; t < NV; t++) {
+    const int k = NV - 1 - t;
     y[k] = rdlane(acc, k) * rd[k];
     acc -= a[k] * y[k];
   }
   T xs[NV], x = 0;
 #pragma unroll
-  for (int k = 0; k < NV; k++) {
+  for (int t = NV - 1; t >= 0; t--) {
+    const int k = NV - 1 - t;
     T s0 = y[k];
 #pragma unroll
     for (int i = 0; i < k; i++)
