@@ -40,6 +40,10 @@ enum {
   TSIDB_P_REW_SIGMA = TSIDB_P_KP_AM + 3, TSIDB_P_REW_CTAU, TSIDB_P_DONE_HEIGHT, TSIDB_P_DONE_TILT,
   TSIDB_P_SELF_COLLISION /* sim: collide the robot<->robot hull pairs as mj_step does (main.py:195); 0 = floor only */,
   TSIDB_P_W_COP /* CoP force task weight (legacy/biped.py:79-80), 0 = not in the stack */,
+  /* closed-loop knobs (all neutral by default = the reference's models): scale of the sim's joint
+   * frictionloss (robot.xml:8), rotor inertia added to the diagonal of TSID's mass matrix on the actuated joints (the sim
+   * has armature 0.005, the URDF none), Coulomb-friction feed-forward added to tau [N m] */
+  TSIDB_P_SIM_FLOSS_SCALE, TSIDB_P_TSID_ARMATURE, TSIDB_P_FRICTION_COMP,
   TSIDB_P_COUNT = 128
 };
 
@@ -123,11 +127,14 @@ int tsidb_step(tsidb_handle h, void *q, void *v, void *qpos, void *qvel, void *q
  * foot_ref / contact_ref / contact_active / com_ref (position, velocity, acceleration) buffers; contact
  * on/off edges re-reference at `frames` [N,2,12] (current sole placements from the last tsidb_tick), as
  * ctrl/WalkController.py:215-253 intends.  t_offset [N] (may be NULL) delays each env's timeline: env e runs
- * on the clock max(t - t_offset[e], 0), so that the envs of one batch need not step in phase. */
+ * on the clock max(t - t_offset[e], 0), so that the envs of one batch need not step in phase.  Contact-timing
+ * feedback (closed loop; td_latch [N] int32, initialised to -1, may be NULL = off): when the last sim step's contact
+ * list (ncon, con_pairs of tsidb_sim / tsidb_step) shows the swing foot on the floor after td_fraction of its
+ * swing, the touch-down is taken at once - the foot is a stance foot for the rest of that step. */
 int tsidb_walk_update(tsidb_handle h, const void *coef, const int32_t *side, const int32_t *nsteps,
                       const void *rest, const void *com, int K, double t, double step_duration, double t_start,
                       double omega, double com_z0, double com_drop, const void *frames, const void *t_offset,
-                      void *stream);
+                      const int32_t *ncon, const int32_t *con_pairs, int32_t *td_latch, double td_fraction, void *stream);
 
 /* probe of formulation.computeProblemData's rigid-body terms (main.py:119): M [N,26,26],
  * hbias [N,26], Jcom [N,3,26], Jf [N,2,6,26] (LOCAL), oMf [N,2,12], com [N,3].  Test/debug use. */

@@ -48,6 +48,7 @@ int or_env_step_batch_walk(const OrModel *m, const double *params, int n, double
                            const double *cop_frames, const double *env_params, double *tau, double *dv, double *f,
                            int32_t *status, double *obs, int32_t *ncon, int32_t *con_geom, int nthreads,
                            const OrWalkTables *w, double *frames, double *rewdone, const double *terrain, const double *cop_ref) {
+  ((OrModel *)m)->floss_scale = params[P_SIM_FLOSS_SCALE] != 0.0 ? params[P_SIM_FLOSS_SCALE] : 1.0;
   const int sim = params[P_SIM_ENABLED] != 0.0;
   const int closed = params[P_CLOSED_LOOP] != 0.0;
   const int quirks = params[P_QUIRKS] != 0.0 && !closed;
@@ -58,11 +59,13 @@ int or_env_step_batch_walk(const OrModel *m, const double *params, int n, double
   for (int e = 0; e < n; e++) {
     double *qe = q + (size_t)e * OR_NQ, *ve = v + (size_t)e * OR_NV;
     if (w)
-      or_walk_update(1, w->coef + (size_t)e * w->K * 16, w->side + (size_t)e * w->K, w->nsteps + e,
-                     w->rest + (size_t)e * (w->K + 1) * 8, w->com + (size_t)e * (w->K + 2) * 6, w->K, w->t,
-                     w->t_off ? w->t_off + e : NULL, w->T, w->t_start, w->omega, w->z0, w->dz, frames + (size_t)e * 24,
-                     foot_ref + (size_t)e * 48, contact_ref + (size_t)e * 24, contact_active + (size_t)e * 2,
-                     com_ref + (size_t)e * 9);
+      or_walk_update_fb(1, w->coef + (size_t)e * w->K * 16, w->side + (size_t)e * w->K, w->nsteps + e,
+                        w->rest + (size_t)e * (w->K + 1) * 8, w->com + (size_t)e * (w->K + 2) * 6, w->K, w->t,
+                        w->t_off ? w->t_off + e : NULL, w->T, w->t_start, w->omega, w->z0, w->dz, frames + (size_t)e * 24,
+                        foot_ref + (size_t)e * 48, contact_ref + (size_t)e * 24, contact_active + (size_t)e * 2,
+                        com_ref + (size_t)e * 9, w->td_latch ? ncon + e : NULL,
+                        w->td_latch ? con_geom + (size_t)e * OR_MAXCON : NULL, w->td_latch ? w->td_latch + e : NULL,
+                        m->foot_body[0], m->foot_body[1], w->td_frac);
     if (closed) sim_to_tsid(m, qpos + (size_t)e * OR_NQ, qvel + (size_t)e * OR_NV, qe, ve);
     int st = or_tsid_tick_cop(m, params, qe, ve, com_ref + (size_t)e * 9, posture_ref + (size_t)e * OR_NA,
                               foot_ref + (size_t)e * 48, contact_ref + (size_t)e * 24, contact_active + (size_t)e * 2,

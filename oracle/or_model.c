@@ -93,6 +93,15 @@ OrModel *or_model_load(const void *blob, size_t nbytes) {
   double s = 0;
   for (int i = 0; i < OR_NV; i++) s += m->mj_dof_M0[i];
   m->meaninertia = s / OR_NV;
+  m->floss_scale = 1.0;
+  {
+    int s2t[OR_NA];
+    m->foot_body[0] = m->foot_body[1] = -1;
+    if (geti(b, "mj_sim2tsid", s2t, OR_NA) == 0)
+      for (int f = 0; f < 2; f++)
+        for (int i = 0; i < OR_NA; i++)
+          if (s2t[i] == m->frame_parent[f] - 1) m->foot_body[f] = 1 + i;
+  }
   return m;
 }
 

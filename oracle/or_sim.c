@@ -409,7 +409,7 @@ int or_sim_step_ext(const OrModel *m, double *qpos, double *qvel, const double *
     e.aref[r] = -bb * qvel[k];
     e.R[r] = fmax(MINVAL, (1 - imp) / imp * m->mj_dof_invw0[k]);
     e.D[r] = 1.0 / e.R[r];
-    e.floss[r] = m->mj_frictionloss[k];
+    e.floss[r] = m->mj_frictionloss[k] * m->floss_scale;
     e.type[r] = 0;
   }
   for (int c = 0; c < ncon; c++) {

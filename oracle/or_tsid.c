@@ -534,6 +534,7 @@ int or_tsid_tick_cop(const OrModel *m, const double *params, double *q, double *
     }
   }
   or_rbd_terms(m, q, v, &t);
+  for (int i = 6; i < OR_NV; i++) t.M[i][i] += params[P_TSID_ARMATURE]; /* closed-loop knob, 0 by default */
   memcpy(or_last_frames, t.oMf, sizeof or_last_frames);
   or_tsid_assemble_cop(m, params, &t, q, v, com_ref, posture_ref, foot_ref, contact_ref, contact_active, cop_ref, &qp);
   int status = or_qp_solve(&qp, (int)params[P_MAX_ITER], &sol);
@@ -556,6 +557,10 @@ int or_tsid_tick_cop(const OrModel *m, const double *params, double *q, double *
         for (int i = 0; i < 6; i++) jc += T[i][c] * t.Jf[fo][i][6 + r];
         a -= jc * f[12 * fo + c];
       }
+    }
+    if (params[P_FRICTION_COMP] != 0.0) { /* closed-loop knob: Coulomb-friction feed-forward */
+      const double sat = (v[6 + r] + params[P_DT] * dv[6 + r]) * 20.0;
+      a += params[P_FRICTION_COMP] * (sat > 1 ? 1.0 : (sat < -1 ? -1.0 : sat));
     }
     tau[r] = a;
   }

@@ -30,7 +30,7 @@ enum {
   P_KP_POSTURE = P_CPOINTS + 12 /*20*/, P_KD_POSTURE = P_KP_POSTURE + 20,
   P_TAU_MAX = P_KD_POSTURE + 20, P_V_MAX = P_TAU_MAX + 20, P_MAX_ITER = P_V_MAX + 20,
   P_SIM_ENABLED, P_CLOSED_LOOP, P_W_AM, P_KP_AM /*3*/, P_REW_SIGMA = P_KP_AM + 3, P_REW_CTAU, P_DONE_HEIGHT, P_DONE_TILT,
-  P_SELF_COLLISION, P_W_COP, P_COUNT = 128
+  P_SELF_COLLISION, P_W_COP, P_SIM_FLOSS_SCALE, P_TSID_ARMATURE, P_FRICTION_COMP, P_COUNT = 128
 };
 
 typedef struct {
@@ -61,6 +61,8 @@ typedef struct {
   double opt[7];     /* dt gz tol iters ls_iters ls_tol impratio */
   double contact[8]; /* mu solref[2] solimp[5] */
   double meaninertia;
+  int foot_body[2];   /* sim bodies carrying the left / right sole frame */
+  double floss_scale; /* closed-loop knob params[P_SIM_FLOSS_SCALE] (1 = robot.xml:8), set by the batch entry points */
   void *owned;
 } OrModel;
 
@@ -170,12 +172,20 @@ void or_walk_update(int n, const double *coef, const int32_t *side, const int32_
                     double z0, double dz, const double *frames, double *foot_ref, double *contact_ref,
                     uint8_t *contact_active, double *com_ref);
 
+void or_walk_update_fb(int n, const double *coef, const int32_t *side, const int32_t *nsteps, const double *rest,
+                       const double *com, int K, double t, const double *t_off, double T, double t_start, double omega,
+                       double z0, double dz, const double *frames, double *foot_ref, double *contact_ref,
+                       uint8_t *contact_active, double *com_ref, const int32_t *ncon, const int32_t *con_geom,
+                       int32_t *latch, int fbody0, int fbody1, double td_frac);
+
 /* walking tables for or_env_step_batch_walk (env-major, layouts as or_walk_update) */
 typedef struct {
   const double *coef, *rest, *com, *t_off;
   const int32_t *side, *nsteps;
   int K;
   double t, T, t_start, omega, z0, dz;
+  int32_t *td_latch; /* [n] contact-timing feedback state or NULL (or_walk_update_fb) */
+  double td_frac;
 } OrWalkTables;
 int or_env_step_batch_walk(const OrModel *m, const double *params, int n, double *q, double *v, double *qpos,
                            double *qvel, double *qacc_ws, double *com_ref, const double *posture_ref,

@@ -45,7 +45,8 @@ class OrSimInfo(C.Structure):
 class OrWalkTables(C.Structure):
     _fields_ = [("coef", C.c_void_p), ("rest", C.c_void_p), ("com", C.c_void_p), ("t_off", C.c_void_p),
                 ("side", C.c_void_p), ("nsteps", C.c_void_p), ("K", C.c_int), ("t", C.c_double), ("T", C.c_double),
-                ("t_start", C.c_double), ("omega", C.c_double), ("z0", C.c_double), ("dz", C.c_double)]
+                ("t_start", C.c_double), ("omega", C.c_double), ("z0", C.c_double), ("dz", C.c_double),
+                ("td_latch", C.c_void_p), ("td_frac", C.c_double)]
 
 
 class WalkTables:
@@ -62,7 +63,10 @@ class WalkTables:
         self.c = OrWalkTables(k["coef"].ctypes.data, k["rest"].ctypes.data, k["com"].ctypes.data,
                               k["t_off"].ctypes.data if k["t_off"] is not None else None, k["side"].ctypes.data,
                               k["nsteps"].ctypes.data, sched.K, 0.0, float(sched.conf.step_duration),
-                              float(sched.t_start), float(sched.omega), float(sched.z0), float(sched.dz))
+                              float(sched.t_start), float(sched.omega), float(sched.z0), float(sched.dz), None, 0.0)
+        if getattr(sched, "td_latch", None) is not None:   # contact-timing feedback: the oracle keeps its own latch
+            k["td_latch"] = np.ascontiguousarray(sched.td_latch[:n].cpu().numpy(), dtype=np.int32)
+            self.c.td_latch, self.c.td_frac = k["td_latch"].ctypes.data, float(sched.td_fraction)
 
     def at(self, t):
         self.c.t = float(t)

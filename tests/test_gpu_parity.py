@@ -936,3 +936,71 @@ def test_cop_force_task_f64(oracle):
     for _ in range(20):
         fresh.step()
     assert int((fresh.status != 0).sum()) == 0
+
+
+def _closed_loop_walker(n, t_start=1.0, seed=1, feedback=0.6):
+    from tsid_control_amd import RobotConfig, WalkController
+    from tsid_control_amd.walk_planner import WalkSchedule, op3_closed_loop_walking_conf, op3_walking_posture
+    conf = op3_closed_loop_walking_conf(RobotConfig())
+    wc = WalkController(conf, num_envs=n, device="cuda:0")
+    wc.posture_ref += torch.as_tensor(op3_walking_posture(), device=wc.device)
+    lf, rf = wc.frames[0, 0, 9:11].cpu().numpy(), wc.frames[0, 1, 9:11].cpu().numpy()
+    sched = WalkSchedule.from_demo_paths(n, conf, wc.device, wc.dtype, seed=seed, q0_feet=(lf, rf),
+                                         com0=wc.com_ref[0, :3].cpu().numpy(), foot_press=0.0, t_start=t_start)
+    if feedback:
+        sched.enable_touchdown_feedback(feedback)
+    return wc, sched, 0.5 * (lf + rf)
+
+
+def test_closed_loop_walking_matches_oracle(oracle):
+    """f-1 completed: the loop closed WHILE walking - every tick reads the sim state (main.py:126-129 turned around),
+    the sim is driven by tau, the schedule's touch-downs follow the sim's contact list - against the oracle doing the
+    same (or_walk_update_fb + tick on the sim state + sim step with motor torques) over the start phase and more than
+    two steps, every contact edge included."""
+    from oracle.oracle import WalkTables
+    n = 6
+    wc, sched, _ = _closed_loop_walker(n, t_start=0.3, seed=4)
+    st = mirror(wc)
+    st["frames"] = wc.frames.cpu().numpy().copy()
+    tables = WalkTables(sched)
+    edges = 0
+    prev = wc.contact_active.clone()
+    for i in range(720):
+        t = i * wc.conf.dt
+        sched.apply(wc, t)
+        wc.step()
+        oracle.env_step_batch(wc.params, st, nthreads=6, walk=tables.at(t))
+        assert np.array_equal(wc.contact_active.cpu().numpy(), st["contact_active"]), i
+        assert np.array_equal(wc.status.cpu().numpy(), st["status"]), i
+        assert np.array_equal(wc.ncon.cpu().numpy(), st["ncon"]), i
+        edges += int((wc.contact_active != prev).sum())
+        prev = wc.contact_active.clone()
+        if i % 20 == 0 or i == 719:
+            assert diff(wc.tau, st["tau"]) < 1e-5 and diff(wc.qpos, st["qpos"]) < 1e-7 and diff(wc.qvel, st["qvel"]) < 1e-5, i
+            assert np.array_equal(wc.con_pairs.cpu().numpy(), st["con_geom"]), i
+    assert edges >= 4 * n and int((sched.td_latch >= 0).sum()) > 0
+    assert np.array_equal(sched.td_latch.cpu().numpy(), tables.keep["td_latch"])
+    assert int((wc.status != 0).sum()) == 0 and float(wc.qpos[:, 2].min()) > 0.29
+
+
+def test_closed_loop_walking_does_not_fall():
+    """64 walkers, 5000 ticks (10 s, 18 steps) with the loop closed: nobody falls, no QP fails, the CoM stays on its
+    LIPM reference, the robots arrive where their footstep plans end."""
+    n = 64
+    wc, sched, start = _closed_loop_walker(n)
+    bad = torch.zeros(n, dtype=torch.bool, device=wc.device)
+    done = torch.zeros(n, dtype=wc.dtype, device=wc.device)
+    worst_tilt = worst_com = 0.0
+    for i in range(5000):
+        sched.apply(wc, i * wc.conf.dt)
+        wc.step()
+        bad |= wc.status != 0
+        done += wc.done
+        if i % 25 == 0:
+            worst_tilt = max(worst_tilt, float(2 * wc.qpos[:, 4:6].norm(dim=1).max()))
+            worst_com = max(worst_com, float((wc.obs[:, 53:55] - wc.com_ref[:, :2]).abs().max()))
+    assert not bool(bad.any()) and float(done.sum()) == 0
+    assert float(wc.qpos[:, 2].min()) > 0.29 and worst_tilt < 0.3 and worst_com < 0.02
+    travelled = (wc.qpos[:, :2] - torch.as_tensor(start, device=wc.device)).norm(dim=1)
+    assert float(travelled.min()) > 0.5
+    assert int((sched.td_latch >= 0).sum()) == n       # every env took at least one touch-down from the sim

@@ -5,7 +5,7 @@ set -e
 OUT=$GRAFT_REPO_ROOT/gpurun_out/${1:-pmc}
 export TMPDIR=/tmp
 cd /tmp
-ARGS="$GRAFT_REPO_ROOT/bench.py --steps 100 --warmup 5 --cpu-seconds 0 --no-overlap"
+ARGS="$GRAFT_REPO_ROOT/bench.py --steps 100 --warmup 5 --cpu-seconds 0 --no-overlap --no-secondary"
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/p1 -- python3 $ARGS > $OUT.p1.log 2>&1
 rocprofv3 --kernel-trace --pmc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQ_IFETCH SQ_ACTIVE_INST_VALU --output-format csv -d $OUT/p2 -- python3 $ARGS > $OUT.p2.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/p3 -- python3 $ARGS > $OUT.p3.log 2>&1

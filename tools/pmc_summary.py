@@ -44,4 +44,16 @@ if tj:
                              "FETCH_SIZE matches the known read byte count 1:1 on this access pattern (8 B per lane, "
                              "env-major rows), so the gfx950 x2 correction for 16 B/lane streams is not applied in "
                              "bytes_per_launch (bytes_per_launch_fetch_x2 applies it)." % (last or "all")}
+    # what the passes were taken on (bench.py reports the traffic only for this configuration) and the issue
+    # counters behind bench.py's "binding_resource": VALU / SALU / LDS instructions per env, wave cycles per env
+    out["measured_on"] = {"dtype": "f64", "envs": 4096, "workload": "walk", "self_collision": 1}
+    out["source"] = ("rocprofv3 --kernel-trace --pmc passes of tools/pmc_profile.sh: bench.py --steps 100 --warmup 5 "
+                     "--no-overlap, last %s dispatches of each kernel" % (last or "all"))
+    out["valu"] = {}
+    for name, kernels in (("k_tick", [k for k in acc if k.startswith("k_tick<double")]), ("k_sim", ["k_sim<double>"])):
+        n_env = 4096.0
+        g = lambda c: sum(mean(k, c) for k in kernels)
+        out["valu"][name] = {"valu_inst_per_env": g("SQ_INSTS_VALU") / n_env, "salu_inst_per_env": g("SQ_INSTS_SALU") / n_env,
+                             "lds_inst_per_env": g("SQ_INSTS_LDS") / n_env, "wave_cycles_per_env": g("SQ_WAVE_CYCLES") / n_env,
+                             "wait_any_cycles_per_env": g("SQ_WAIT_ANY") / n_env}
     json.dump(out, open(tj, "w"), indent=1)

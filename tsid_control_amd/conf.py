@@ -96,6 +96,9 @@ class RobotConfig:
     self_collision = True      # sim stage collides the robot<->robot convex-hull pairs, as mj_step does (main.py:195);
     #                            False = floor contacts only (round-1 behaviour)
     w_cop = 0.0                # CoP force task of legacy/biped.py:79-80 (legacy/op3_conf.py:14 uses 0); 0 = off
+    sim_frictionloss_scale = 1.0   # closed-loop knobs, neutral = the reference's models: scale of the sim's joint frictionloss
+    tsid_armature = 0.0            #   (robot.xml:8), rotor inertia on the diagonal of TSID's M (the sim has 0.005, the URDF none),
+    friction_compensation = 0.0    #   Coulomb-friction feed-forward in tau [N m] (direction of the commanded joint velocity)
     reward_com_sigma = 0.05    # reward = exp(-|com - com_ref|^2 / sigma^2) - reward_torque_cost * |tau|^2   (per tick)
     reward_torque_cost = 1e-3
     done_base_height = 0.2     # done = failed QP, base lower than this [m], or tilted by more than done_tilt_deg

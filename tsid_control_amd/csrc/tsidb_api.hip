@@ -178,7 +178,8 @@ __global__ __launch_bounds__(WAVE) void k_reset(const DevModel<T> *__restrict__ 
 template <typename T>
 __global__ __launch_bounds__(256) void k_walk(int n, const T *coef, const int *side, const int *nsteps, const T *rest, const T *com,
                                               int K, T t_now, const T *t_off, T Tstep, T t_start, T omega, T z0, T dz, const T *frames, T *foot_ref,
-                                              T *contact_ref, uint8_t *cact, T *com_ref) {
+                                              T *contact_ref, uint8_t *cact, T *com_ref, const int *ncon, const int *con, int *latch,
+                                              int fbody0, int fbody1, T td_frac) {
   // 16 lanes per env: every lane evaluates the (cheap) polynomials, each writes its share of the rows, so
   // the table reads hit one line per env and the reference rows are written as contiguous runs
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -197,6 +198,21 @@ __global__ __launch_bounds__(256) void k_walk(int n, const T *coef, const int *s
   const int kc = kk < (ns > 0 ? ns - 1 : 0) ? kk : (ns > 0 ? ns - 1 : 0);
   const int sd = side[E * K + kc];
   const int kr = kk < ns ? kk : ns;
+  // contact-timing feedback (closed loop): if the sim reported the swing foot on the floor in the last part of its
+  // swing, the step's touch-down is taken now - the foot counts as a stance foot for the rest of step k (latched per
+  // env), so the contact is added at the placement the foot really has
+  bool early = false;
+  if (latch) {
+    const int lk = latch[e];
+    early = walking && lk == k;
+    if (walking && !early && s > td_frac * Tstep) {
+      const int fb = sd == 0 ? fbody0 : fbody1, nc = ncon[e];
+      for (int c = 0; c < nc; c++) {
+        const int cp = con[E * MAXCON + c];
+        if ((cp >> 16) == fb && !(cp & 0x8000)) early = true;
+      }
+    }
+  }
   const bool act[2] = {cact[E * 2] != 0, cact[E * 2 + 1] != 0}; // read by every lane before lane 0 rewrites them
   const T *c = coef + (E * K + kc) * 16;
   const T pw[4] = {T(1), s, s * s, s * s * s}, d1[4] = {T(0), T(1), 2 * s, 3 * s * s}, d2[4] = {T(0), T(0), T(2), 6 * s};
@@ -209,7 +225,7 @@ __global__ __launch_bounds__(256) void k_walk(int n, const T *coef, const int *s
   }
 #pragma unroll
   for (int f = 0; f < 2; f++) {
-    const bool swing = walking && sd == f;
+    const bool swing = walking && sd == f && !early;
     const T *rs = rest + ((E * (K + 1) + kr) * 2 + f) * 4;
     const T x = swing ? pos[0] : rs[0], y = swing ? pos[1] : rs[1], z = swing ? pos[2] : rs[3], yaw = swing ? pos[3] : rs[2];
     const T cy = cos(yaw), sy = sin(yaw);
@@ -241,6 +257,7 @@ __global__ __launch_bounds__(256) void k_walk(int n, const T *coef, const int *s
       if (swing && active) cact[E * 2 + f] = 0;
     }
   }
+  if (latch && r == 0 && early) latch[e] = k; // (every lane of the env read the old value above: same wavefront)
   // CoM reference: LIPM segment (zmp, d, c) of the current phase in the plane, quintic descent in height
   if (r < 9) {
     const int ph = k + 1 < ns + 1 ? k + 1 : ns + 1;
@@ -370,6 +387,7 @@ struct tsidb_ctx {
   const void *com_ref = nullptr, *posture_ref = nullptr, *foot_ref = nullptr, *contact_ref = nullptr, *cop_frames = nullptr;
   const uint8_t *contact_active = nullptr;
   const void *env_params = nullptr, *terrain = nullptr, *cop_ref = nullptr;
+  int foot_body[2] = {-1, -1}; // sim bodies that carry the left / right sole frame
   std::string err;
 };
 
@@ -489,7 +507,7 @@ static void build_model(tsidb_ctx *h, DevModel<T> &m) {
   const double *bw = b.f64("mj_body_invw0", NB * 2), *M0 = b.f64("mj_dof_M0", NV);
   double mean = 0;
   for (int i = 0; i < NV; i++) {
-    m.mj_armature[i] = (T)arm[i]; m.mj_frictionloss[i] = (T)fl[i]; m.mj_dof_invw0[i] = (T)iw[i];
+    m.mj_armature[i] = (T)arm[i]; m.mj_frictionloss[i] = (T)(fl[i] * P[P_SIM_FLOSS_SCALE]); m.mj_dof_invw0[i] = (T)iw[i];
     mean += M0[i];
   }
   m.meaninertia = (T)(mean / NV);
@@ -628,6 +646,13 @@ int tsidb_create(const void *model_blob, size_t nbytes, const double *params, in
     if (device < 0 || device >= ndev) throw std::string("no such HIP device (this library has no CPU path)");
     HIP_OK(hipSetDevice(device));
     if (dtype == TSIDB_F64) upload_model<double>(h); else upload_model<float>(h);
+    { // sim body of each sole frame: frame -> TSID joint -> sim joint (mj_sim2tsid) -> body
+      const int *fp = h->blob.i32("pin_frame_parent", 2), *s2t = h->blob.i32("mj_sim2tsid", NA);
+      for (int f = 0; f < 2; f++)
+        for (int i = 0; i < NA; i++)
+          if (s2t[i] == fp[f] - 1) h->foot_body[f] = 1 + i;
+      if (h->foot_body[0] < 0 || h->foot_body[1] < 0) throw std::string("model blob: sole frames are not on sim bodies");
+    }
   } catch (const std::string &s) {
     h->err = s;
     return 1;
@@ -739,23 +764,26 @@ int tsidb_step(tsidb_handle h, void *q, void *v, void *qpos, void *qvel, void *q
 
 int tsidb_walk_update(tsidb_handle h, const void *coef, const int32_t *side, const int32_t *nsteps, const void *rest,
                       const void *com, int K, double t, double step_duration, double t_start, double omega, double com_z0,
-                      double com_drop, const void *frames, const void *t_offset, void *stream) {
+                      double com_drop, const void *frames, const void *t_offset, const int32_t *ncon, const int32_t *con_pairs,
+                      int32_t *td_latch, double td_fraction, void *stream) {
   GUARD_BEGIN
   need_refs(h);
   if (!coef || !side || !nsteps || !rest || !com || !frames || K <= 0) throw std::string("tsidb_walk_update: null table or K <= 0");
   if (!(step_duration > 0) || !(omega > 0) || t_start < 0) throw std::string("tsidb_walk_update: bad timing");
+  if (td_latch && (!ncon || !con_pairs)) throw std::string("tsidb_walk_update: touch-down feedback needs ncon and con_pairs");
   hipStream_t s = (hipStream_t)stream;
   const int grid = (h->num_envs * 16 + 255) / 256;
   if (h->dtype == TSIDB_F64)
     hipLaunchKernelGGL(k_walk<double>, dim3(grid), dim3(256), 0, s, h->num_envs, (const double *)coef, side, nsteps,
                        (const double *)rest, (const double *)com, K, t, (const double *)t_offset, step_duration, t_start, omega, com_z0, com_drop,
                        (const double *)frames, (double *)h->foot_ref, (double *)h->contact_ref, (uint8_t *)h->contact_active,
-                       (double *)h->com_ref);
+                       (double *)h->com_ref, ncon, con_pairs, td_latch, h->foot_body[0], h->foot_body[1], td_fraction);
   else
     hipLaunchKernelGGL(k_walk<float>, dim3(grid), dim3(256), 0, s, h->num_envs, (const float *)coef, side, nsteps,
                        (const float *)rest, (const float *)com, K, (float)t, (const float *)t_offset, (float)step_duration, (float)t_start, (float)omega,
                        (float)com_z0, (float)com_drop, (const float *)frames, (float *)h->foot_ref, (float *)h->contact_ref,
-                       (uint8_t *)h->contact_active, (float *)h->com_ref);
+                       (uint8_t *)h->contact_active, (float *)h->com_ref, ncon, con_pairs, td_latch, h->foot_body[0], h->foot_body[1],
+                       (float)td_fraction);
   HIP_OK(hipGetLastError());
   GUARD_END
 }

@@ -996,6 +996,10 @@ __device__ __forceinline__ void tsid_tick_env(const DevModel<T> &m, TickLds<T> &
   }
   __syncthreads();
   rbd_terms(m, L, lane);
+  if (m.params[P_TSID_ARMATURE] != 0) { // closed-loop knob: rotor inertia of the actuated joints in TSID's model
+    if (lane >= 6 && lane < NV) L.Dyn[lane * LDD + lane] += m.params[P_TSID_ARMATURE];
+    __syncthreads();
+  }
   TSIDB_STAMP(1);
 
   QpCtx<T> c;
@@ -1117,6 +1121,10 @@ __device__ __forceinline__ void tsid_tick_env(const DevModel<T> &m, TickLds<T> &
   if (lane < NA) {
     T t = L.h[6 + lane];
     for (int e = 0; e < n; e++) t += L.Dyn[(6 + lane) * LDD + e] * L.x[e];
+    if (m.params[P_FRICTION_COMP] != 0) { // Coulomb-friction feed-forward along the commanded joint velocity
+      const T vn = L.vs[6 + lane] + m.params[P_DT] * L.x[6 + lane], sat = vn * T(20);
+      t += m.params[P_FRICTION_COMP] * (sat > 1 ? T(1) : (sat < -1 ? T(-1) : sat));
+    }
     tau[lane] = t;
     tau2 = t * t;
   }

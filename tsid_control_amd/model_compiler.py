@@ -503,28 +503,12 @@ def emit_topology_header(mj_parent, path: Path):
                 if a != k - 5 and (anc_body[k - 5] >> a) & 1:
                     m |= 0x3F if a == 0 else 1 << (5 + a)
             dofanc.append(m)
-    # elimination order of the tree-sparse factorisation: children before parents (any such order gives the same
-    # factor), interleaved across the branches by height above the leaves, so that consecutive pivots are
-    # independent and their latencies overlap; the dense root block last
-    height = [0] * nv
-    for k in range(nv - 1, 5, -1):
-        b = k - 5
-        p = int(mj_parent[b])
-        if p > 0:
-            height[5 + p] = max(height[5 + p], height[k] + 1)
-    order = sorted(range(6, nv), key=lambda k: (height[k], k)) + [5, 4, 3, 2, 1, 0]
-    # 1 after the last pivot of each group of mutually independent pivots (a scheduling fence goes there)
-    fence = [1 if (t + 1 == len(order) or order[t + 1] < 6 or height[order[t + 1]] != height[order[t]]) else 0
-             for t in range(len(order))]
     txt = ("// GENERATED by tsid_control_amd/model_compiler.py from the sim tree of the compiled model blob.\n"
            "// MJ_DOFANC[k]: bitmask of the dofs that are strict ancestors of dof k (lower indices).\n"
-           "// MJ_ELIM_ORDER: pivots of the tree-sparse factorisation, children before parents, branches interleaved.\n"
            "#pragma once\nnamespace tsidb {\n"
            f"constexpr int TOPO_NB = {nb};\n"
            "constexpr int TOPO_PARENT[] = {" + ", ".join(str(int(x)) for x in mj_parent) + "};\n"
            "constexpr unsigned MJ_DOFANC[] = {" + ", ".join(hex(x) + "u" for x in dofanc) + "};\n"
-           "constexpr int MJ_ELIM_ORDER[] = {" + ", ".join(str(x) for x in order) + "};\n"
-           "constexpr int MJ_ELIM_FENCE[] = {" + ", ".join(str(x) for x in fence) + "};\n"
            "} // namespace tsidb\n")
     path.write_text(txt)
 

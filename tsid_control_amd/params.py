@@ -38,6 +38,9 @@ P_DONE_HEIGHT = 120
 P_DONE_TILT = 121
 P_SELF_COLLISION = 122
 P_W_COP = 123
+P_SIM_FLOSS_SCALE = 124
+P_TSID_ARMATURE = 125
+P_FRICTION_COMP = 126
 P_COUNT = 128
 
 
@@ -85,6 +88,9 @@ def pack_params(conf, effort_limit, velocity_limit):
     p[P_DONE_TILT] = np.cos(np.deg2rad(getattr(conf, "done_tilt_deg", 45.0)))
     p[P_SELF_COLLISION] = 1.0 if getattr(conf, "self_collision", True) else 0.0
     p[P_W_COP] = getattr(conf, "w_cop", 0.0)
+    p[P_SIM_FLOSS_SCALE] = getattr(conf, "sim_frictionloss_scale", 1.0)
+    p[P_TSID_ARMATURE] = getattr(conf, "tsid_armature", 0.0)
+    p[P_FRICTION_COMP] = getattr(conf, "friction_compensation", 0.0)
     if p[P_CLOSED_LOOP] and not p[P_SIM_ENABLED]:
         raise ValueError("closed_loop needs the sim stage (sim_enabled=True)")
     return p

@@ -55,6 +55,30 @@ def op3_walking_conf(conf: RobotConfig = None) -> RobotConfig:
     return c
 
 
+def op3_closed_loop_walking_conf(conf: RobotConfig = None) -> RobotConfig:
+    """Walking with the loop closed (TSID reads the sim state each tick, the sim is driven by tau).
+    On top of op3_walking_conf, what a controller needs once its torques meet the sim's model instead of its own:
+      - the contact rectangle INSIDE the real sole: the reference's rectangle (conf.py:31-34, +-0.055 in x,
+        +-0.0275 in y) has x and y swapped against the collision mesh (0.055 wide in x, 0.13 long in y; SURVEY.md F6d,
+        legacy/op3_conf.py:24-27 has it the right way round) - a centre of pressure TSID believes feasible would tip
+        the real foot over its edge;
+      - the sim's rotor inertia (armature 0.005, robot.xml:8) in TSID's mass matrix and a feed-forward for its joint
+        Coulomb friction (frictionloss 0.1 N m): the URDF has neither;
+      - stiffer contact and CoM gains.
+    Use WalkSchedule(..., foot_press=0) with it (the swing foot is aimed AT the floor, not into it) and
+    enable_touchdown_feedback().  64 envs walk 5000 ticks (18 steps) without a fall
+    (tests/test_gpu_parity.py::test_closed_loop_walking_does_not_fall)."""
+    c = op3_walking_conf(conf)
+    c.reference_quirks = False
+    c.closed_loop = True
+    c.lxn = c.lxp = 0.02
+    c.lyn = c.lyp = 0.05
+    c.tsid_armature = 0.005
+    c.friction_compensation = 0.1
+    c.kp_contact, c.kp_com = 400.0, 40.0
+    return c
+
+
 def op3_walking_posture(bend=0.45):
     """Posture-task reference for walking: knees bent by 2*bend with the feet kept flat under the hips
     (TSID joint order: left leg hip pitch / knee / ankle pitch = joints 4, 5, 6, right leg 13, 14, 15; the
@@ -150,6 +174,13 @@ class WalkSchedule:
         self.N, self.K = N, K
         self.device, self.dtype = device, dtype
         self.t_offset = None  # [N] per-env start delay (set_phase_offsets); None = every env on the same clock
+        self.td_latch, self.td_fraction = None, 0.6  # contact-timing feedback (enable_touchdown_feedback)
+
+    def enable_touchdown_feedback(self, fraction=0.6):
+        """Closed loop: take a step's touch-down as soon as the sim reports the swing foot on the floor after
+        `fraction` of its swing (instead of at the scheduled time); device path (apply) only."""
+        self.td_latch = torch.full((self.N,), -1, dtype=torch.int32, device=self.device)
+        self.td_fraction = float(fraction)
 
     def set_phase_offsets(self, t_offset):
         """De-phase the batch: env e follows its timeline on the clock max(t - t_offset[e], 0), so that single-
@@ -266,5 +297,8 @@ class WalkSchedule:
                                          p(self._com_c), self.K, float(t), float(self.conf.step_duration),
                                          float(self.t_start), float(self.omega), float(self.z0), float(self.dz),
                                          p(wc.frames), p(self.t_offset) if self.t_offset is not None else None,
+                                         p(wc.ncon) if self.td_latch is not None else None,
+                                         p(wc.con_pairs) if self.td_latch is not None else None,
+                                         p(self.td_latch) if self.td_latch is not None else None, float(self.td_fraction),
                                          wc._stream())
         _lib.check(wc._L, wc._h, rc, "tsidb_walk_update")
