@@ -667,6 +667,7 @@ def test_golden_foot_trajectories_through_the_device_kernel():
         sched = WalkSchedule.__new__(WalkSchedule)
         sched.conf = type("C", (), {"step_duration": t1 - t0})()
         sched.N, sched.K, sched.device, sched.dtype, sched.t_offset = 1, 1, wc.device, wc.dtype, None
+        sched.td_latch, sched.td_fraction = None, 0.6
         sched.t_start, sched.omega, sched.z0, sched.dz = 0.0, 3.0, 0.24, 0.0
         dev = lambda a, dt=wc.dtype: torch.as_tensor(np.asarray(a), device=wc.device).to(dt)
         sched.coef = dev(tr.coefficients()[None, None])
