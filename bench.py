@@ -69,6 +69,10 @@ def parse():
                          "ticks mix in one launch")
     ap.add_argument("--tau-max-scaling", type=float, default=None,
                     help="override conf.tau_max_scaling (ctrl/conf.py:69; 5.0): small values make torque bounds active")
+    ap.add_argument("--graph", type=int, default=0,
+                    help="N = 1, walk workload: capture this many pipelined steps in ONE HIP graph (WalkController.capture_steps) "
+                         "and replay it - one launch instead of ~8 host calls per step; per-kernel event timing is not "
+                         "available inside a graph")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary measurements (N = 1 only)")
     ap.add_argument("--secondary-steps", type=int, default=200)
     ap.add_argument("--event-every", type=int, default=int(os.environ.get("TSIDB_EVENT_EVERY", "8")),
@@ -230,6 +234,7 @@ def run_workload(a, dev, rank, world, n, with_gather=True):
         else:
             gather(wc.gather_rows())
 
+    graph_steps = getattr(a, "graph", 0) if (gather is None or world == 1) and overlap and sched is not None else 0
     failed_any = torch.zeros(n, dtype=torch.bool, device=dev)
     loop_frac = torch.zeros((), dtype=torch.float32, device=dev)   # envs in the dual active-set loop, mean over samples
     ds_frac = torch.zeros((), dtype=torch.float32, device=dev)
@@ -246,16 +251,34 @@ def run_workload(a, dev, rank, world, n, with_gather=True):
     if world > 1 and with_gather:
         dist.barrier()
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for k in range(a.steps):
-        one_step(pre + a.warmup + k, k)
-        if k % stride == stride - 1 or k == a.steps - 1:
-            failed_any |= wc.status != 0   # sampled: one tiny kernel, not per step
+    if graph_steps:
+        if a.steps % graph_steps:
+            raise SystemExit("--steps must be a multiple of --graph")
+        wc.t = (pre + a.warmup) * conf.dt
+        graph = wc.capture_steps(graph_steps, sched)
+        graph.replay()                     # first launch uploads the graph: outside the timed region
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(a.steps // graph_steps):
+            graph.replay()
+            if gather is not None:
+                gather(wc.gather_rows())
+            failed_any |= wc.status != 0
             n_samples += 1
-        if k % 16 == 0:                    # device-side accumulation, no host sync
             loop_frac += (wc.info[:, 0] > 1).float().mean()
             ds_frac += (wc.contact_active.sum(dim=1) == 2).float().mean()
             n_stat += 1
+    else:
+        t0 = time.perf_counter()
+        for k in range(a.steps):
+            one_step(pre + a.warmup + k, k)
+            if k % stride == stride - 1 or k == a.steps - 1:
+                failed_any |= wc.status != 0   # sampled: one tiny kernel, not per step
+                n_samples += 1
+            if k % 16 == 0:                    # device-side accumulation, no host sync
+                loop_frac += (wc.info[:, 0] > 1).float().mean()
+                ds_frac += (wc.contact_active.sum(dim=1) == 2).float().mean()
+                n_stat += 1
     torch.cuda.synchronize()
     if world > 1 and with_gather:
         dist.barrier()
@@ -268,8 +291,11 @@ def run_workload(a, dev, rank, world, n, with_gather=True):
     torch.cuda.synchronize()
 
     evs = [e for e in ev if e is not None]
-    tick_ms = sum(e[0].elapsed_time(e[1]) for e in evs) / len(evs)
-    sim_ms = sum(e[2].elapsed_time(e[3]) for e in evs) / len(evs)
+    if graph_steps:
+        tick_ms = sim_ms = float("nan")    # no HIP events inside a captured graph
+    else:
+        tick_ms = sum(e[0].elapsed_time(e[1]) for e in evs) / len(evs)
+        sim_ms = sum(e[2].elapsed_time(e[3]) for e in evs) / len(evs)
     qp_it = wc.info[:, 0].float()
     stats = {"qp_iters_mean": float(qp_it.mean()), "qp_iters_max": int(qp_it.max()),
              "frac_envs_in_active_set_loop": float((qp_it > 1).float().mean()),
@@ -285,7 +311,8 @@ def run_workload(a, dev, rank, world, n, with_gather=True):
              "done_envs_last_step": int(wc.done.sum().item()),
              "com_tracking_err_max_m": float((wc.obs[:, 53:56] - wc.com_ref[:, :3]).abs().max()),
              "base_height_min_m": float(wc.q[:, 2].min())}
-    res = dict(el=el, tick_ms=tick_ms, sim_ms=sim_ms, stats=stats, pre=pre, overlap=overlap, side_gather=side_gather)
+    res = dict(el=el, tick_ms=tick_ms, sim_ms=sim_ms, stats=stats, pre=pre, overlap=overlap, side_gather=side_gather,
+               graph_steps=graph_steps)
     return res, wc, sched, (pre + a.warmup + a.steps) * conf.dt
 
 
@@ -307,7 +334,7 @@ def workload_name(a, n):
 def secondary_runs(a, dev):
     """The unfavourable paths beside the headline, each a short run of its own."""
     out = {}
-    base = dict(dtype=a.dtype, randomize=False, dephase=0.0, tau_max_scaling=None, steps=a.secondary_steps, warmup=20,
+    base = dict(dtype=a.dtype, randomize=False, dephase=0.0, tau_max_scaling=None, graph=0, steps=a.secondary_steps, warmup=20,
                 preroll=600, event_every=4, no_overlap=a.no_overlap, sync_gather=False, self_collision=a.self_collision)
     cases = [
         ("cfg2_stand_1024", dict(workload="stand", steps=max(a.secondary_steps, 400), warmup=200), 1024),
@@ -318,13 +345,19 @@ def secondary_runs(a, dev):
         # torque bounds at 1.2 N m (the gait needs up to 2.3 N m) with the envs spread over one step period: at any
         # tick a good part of the batch is in the dual active-set loop (frac_envs_in_active_set_loop_window_mean)
         ("cfg3_walk_4096_tight_torque_bounds", dict(workload="walk", tau_max_scaling=0.12, dephase=0.5, preroll=800), 4096),
+        # the per-GPU share of the 4096 walkers at 8 GPUs (strong split): a step is one wavefront's latency (k_sim's);
+        # capturing the steps in a HIP graph (one launch per 16 steps) does not help - the host is not the bound
+        ("cfg3_walk_512_eager", dict(workload="walk", steps=800), 512),
+        ("cfg3_walk_512_graph16", dict(workload="walk", steps=800, graph=16), 512),
     ]
     for name, over, n in cases:
         b = SimpleNamespace(**{**base, **over})
         res, wc, _, _ = run_workload(b, dev, 0, 1, n, with_gather=False)
         out[name] = {"workload": workload_name(b, n), "value": n * b.steps / res["el"], "unit": "env-steps/s",
-                     "steps": b.steps, "ms_per_step": 1e3 * res["el"] / b.steps, "k_tick_ms": res["tick_ms"],
-                     "k_sim_ms": res["sim_ms"], "last_step_stats": res["stats"]}
+                     "steps": b.steps, "ms_per_step": 1e3 * res["el"] / b.steps,
+                     "k_tick_ms": None if res["graph_steps"] else res["tick_ms"],
+                     "k_sim_ms": None if res["graph_steps"] else res["sim_ms"],
+                     "hip_graph_steps_per_launch": res["graph_steps"], "last_step_stats": res["stats"]}
         del wc
         torch.cuda.empty_cache()
     return out
@@ -353,6 +386,14 @@ def main():
     el, tick_ms, sim_ms = res["el"], res["tick_ms"], res["sim_ms"]
 
     wsz = 8 if args.dtype == "f64" else 4
+    if res["graph_steps"]:
+        # no HIP events inside a captured graph: take the per-kernel times from a short eager run of the same workload
+        import copy
+        ea = copy.copy(args)
+        ea.graph, ea.steps = 0, 64
+        er, ewc, _, _ = run_workload(ea, dev, rank, world, n, with_gather=False)
+        tick_ms, sim_ms = er["tick_ms"], er["sim_ms"]
+        del ewc
     dom, dom_ms, dom_words = ("k_tick", tick_ms, TICK_WORDS) if tick_ms >= sim_ms else ("k_sim", sim_ms, SIM_WORDS)
     if args.randomize and dom == "k_sim":
         dom_words += 8 + 20  # env_params row + terrain table row
@@ -386,7 +427,8 @@ def main():
                        "envs_per_gpu": n, "global_envs": n * world, "preroll_steps": res["pre"],
                        "parallelism": f"env-sharded x{world}, all-gather of obs + reward + done"
                                       + (" on a side stream" if res["side_gather"] else ""),
-                       "streams": "sim(t) overlapped with tick(t+1) on a second HIP stream" if res["overlap"] else "single stream",
+                       "streams": ("sim(t) overlapped with tick(t+1) on a second HIP stream" if res["overlap"] else "single stream")
+                                  + (f"; {res['graph_steps']} steps per HIP graph launch" if res["graph_steps"] else ""),
                        "qp_failed_envs_last_step": res["stats"]["qp_failed_envs_last_step"], "last_step_stats": res["stats"]},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,

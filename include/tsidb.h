@@ -130,11 +130,14 @@ int tsidb_step(tsidb_handle h, void *q, void *v, void *qpos, void *qvel, void *q
  * on the clock max(t - t_offset[e], 0), so that the envs of one batch need not step in phase.  Contact-timing
  * feedback (closed loop; td_latch [N] int32, initialised to -1, may be NULL = off): when the last sim step's contact
  * list (ncon, con_pairs of tsidb_sim / tsidb_step) shows the swing foot on the floor after td_fraction of its
- * swing, the touch-down is taken at once - the foot is a stance foot for the rest of that step. */
+ * swing, the touch-down is taken at once - the foot is a stance foot for the rest of that step.  t_device (may be
+ * NULL): one value of the path's arithmetic type in device memory that replaces `t` - the launch can then be captured
+ * in a HIP graph and replayed while the caller advances the clock on the device. */
 int tsidb_walk_update(tsidb_handle h, const void *coef, const int32_t *side, const int32_t *nsteps,
                       const void *rest, const void *com, int K, double t, double step_duration, double t_start,
                       double omega, double com_z0, double com_drop, const void *frames, const void *t_offset,
-                      const int32_t *ncon, const int32_t *con_pairs, int32_t *td_latch, double td_fraction, void *stream);
+                      const int32_t *ncon, const int32_t *con_pairs, int32_t *td_latch, double td_fraction,
+                      const void *t_device, void *stream);
 
 /* probe of formulation.computeProblemData's rigid-body terms (main.py:119): M [N,26,26],
  * hbias [N,26], Jcom [N,3,26], Jf [N,2,6,26] (LOCAL), oMf [N,2,12], com [N,3].  Test/debug use. */

@@ -1005,3 +1005,36 @@ def test_closed_loop_walking_does_not_fall():
     travelled = (wc.qpos[:, :2] - torch.as_tensor(start, device=wc.device)).norm(dim=1)
     assert float(travelled.min()) > 0.5
     assert int((sched.td_latch >= 0).sum()) == n       # every env took at least one touch-down from the sim
+
+
+def test_captured_graph_equals_eager_steps():
+    """capture_steps(): k_walk + k_tick + k_sim of several pipelined steps in one HIP graph with the clock on the
+    device - replaying it gives, bit for bit, what the same number of eager pipelined steps give."""
+    from tsid_control_amd.walk_planner import WalkSchedule, op3_walking_posture
+
+    def walker():
+        wc = make(64, walking=True, reference_quirks=False)
+        wc.posture_ref += torch.as_tensor(op3_walking_posture(), device=wc.device)
+        lf, rf = wc.frames[0, 0, 9:11].cpu().numpy(), wc.frames[0, 1, 9:11].cpu().numpy()
+        sched = WalkSchedule.from_demo_paths(64, wc.conf, wc.device, wc.dtype, seed=2, q0_feet=(lf, rf),
+                                             com0=wc.com_ref[0, :3].cpu().numpy(), t_start=0.2)
+        sched.set_phase_offsets(torch.linspace(0.0, 0.3, 64, dtype=torch.float64))
+        return wc, sched
+
+    a, sa = walker()
+    b, sb = walker()
+    for i in range(40):                                # some eager steps first, on both
+        sa.apply(a, i * a.conf.dt); a.step_pipelined()
+        sb.apply(b, i * b.conf.dt); b.step_pipelined()
+    graph = b.capture_steps(8, sb)
+    for r in range(30):                                # 240 steps: through lift-off and touch-down edges
+        for k in range(8):
+            sa.apply(a, a.t); a.step_pipelined()
+        graph.replay()
+    a.sync_sim(); b.sync_sim()
+    torch.cuda.synchronize()
+    assert abs(a.t - b.t) < 1e-12 and abs(float(b.t_device) - b.t) < 1e-9
+    for k in ("q", "v", "tau", "dv", "f", "status", "rows", "qpos", "qvel", "qacc_warmstart", "ncon", "con_pairs", "contact_active",
+              "foot_ref", "com_ref"):
+        assert torch.equal(getattr(a, k), getattr(b, k)), k
+    assert int((b.contact_active.sum(dim=1) == 1).sum()) > 0

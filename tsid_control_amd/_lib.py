@@ -43,7 +43,7 @@ def load():
     L.tsidb_lds_bytes.argtypes = [C.c_int, C.c_int]
     L.tsidb_set_env_params.argtypes = [vp, vp, vp]
     L.tsidb_set_cop_ref.argtypes = [vp, vp]
-    L.tsidb_walk_update.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int] + [C.c_double] * 6 + [vp, vp, vp, vp, vp, C.c_double, vp]
+    L.tsidb_walk_update.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int] + [C.c_double] * 6 + [vp, vp, vp, vp, vp, C.c_double, vp, vp]
     for s in SYMBOLS:
         if s != "tsidb_last_error":
             getattr(L, s).restype = C.c_int

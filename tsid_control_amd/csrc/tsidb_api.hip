@@ -179,7 +179,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void k_walk(int n, const T *coef, const int *side, const int *nsteps, const T *rest, const T *com,
                                               int K, T t_now, const T *t_off, T Tstep, T t_start, T omega, T z0, T dz, const T *frames, T *foot_ref,
                                               T *contact_ref, uint8_t *cact, T *com_ref, const int *ncon, const int *con, int *latch,
-                                              int fbody0, int fbody1, T td_frac) {
+                                              int fbody0, int fbody1, T td_frac, const T *t_dev) {
   // 16 lanes per env: every lane evaluates the (cheap) polynomials, each writes its share of the rows, so
   // the table reads hit one line per env and the reference rows are written as contiguous runs
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256) void k_walk(int n, const T *coef, const int *s
   if (e >= n) return;
   const size_t E = (size_t)e;
   // per-env start delay (de-phased schedules): the env's own clock starts at t_off[e]
-  T t = t_now;
+  T t = t_dev ? t_dev[0] : t_now; // device clock: a captured graph replays with the time it finds there
   if (t_off) { t -= t_off[e]; t = t > 0 ? t : T(0); }
   // timeline: [0, t_start) both feet down; step k in [t_start + k T, t_start + (k+1) T); then the final stand
   const int k = t < t_start ? -1 : (int)floor((t - t_start) / Tstep);
@@ -765,7 +765,7 @@ int tsidb_step(tsidb_handle h, void *q, void *v, void *qpos, void *qvel, void *q
 int tsidb_walk_update(tsidb_handle h, const void *coef, const int32_t *side, const int32_t *nsteps, const void *rest,
                       const void *com, int K, double t, double step_duration, double t_start, double omega, double com_z0,
                       double com_drop, const void *frames, const void *t_offset, const int32_t *ncon, const int32_t *con_pairs,
-                      int32_t *td_latch, double td_fraction, void *stream) {
+                      int32_t *td_latch, double td_fraction, const void *t_device, void *stream) {
   GUARD_BEGIN
   need_refs(h);
   if (!coef || !side || !nsteps || !rest || !com || !frames || K <= 0) throw std::string("tsidb_walk_update: null table or K <= 0");
@@ -777,13 +777,14 @@ int tsidb_walk_update(tsidb_handle h, const void *coef, const int32_t *side, con
     hipLaunchKernelGGL(k_walk<double>, dim3(grid), dim3(256), 0, s, h->num_envs, (const double *)coef, side, nsteps,
                        (const double *)rest, (const double *)com, K, t, (const double *)t_offset, step_duration, t_start, omega, com_z0, com_drop,
                        (const double *)frames, (double *)h->foot_ref, (double *)h->contact_ref, (uint8_t *)h->contact_active,
-                       (double *)h->com_ref, ncon, con_pairs, td_latch, h->foot_body[0], h->foot_body[1], td_fraction);
+                       (double *)h->com_ref, ncon, con_pairs, td_latch, h->foot_body[0], h->foot_body[1], td_fraction,
+                       (const double *)t_device);
   else
     hipLaunchKernelGGL(k_walk<float>, dim3(grid), dim3(256), 0, s, h->num_envs, (const float *)coef, side, nsteps,
                        (const float *)rest, (const float *)com, K, (float)t, (const float *)t_offset, (float)step_duration, (float)t_start, (float)omega,
                        (float)com_z0, (float)com_drop, (const float *)frames, (float *)h->foot_ref, (float *)h->contact_ref,
                        (uint8_t *)h->contact_active, (float *)h->com_ref, ncon, con_pairs, td_latch, h->foot_body[0], h->foot_body[1],
-                       (float)td_fraction);
+                       (float)td_fraction, (const float *)t_device);
   HIP_OK(hipGetLastError());
   GUARD_END
 }

@@ -281,10 +281,11 @@ class WalkSchedule:
         out[:, 2], out[:, 5], out[:, 8] = self.z0 - self.dz * sz, -self.dz * dsz, -self.dz * ddsz
         return out
 
-    def apply(self, wc, t: float):
+    def apply(self, wc, t: float, t_device=None):
         """Device path of one tick's reference update: foot samples, contact switching and the CoM
         reference for every env in one kernel (tsidb_walk_update); equivalent to
-        wc.update_tasks(*self.sample(t)) followed by wc.com_ref[:] = self.com_ref(t)."""
+        wc.update_tasks(*self.sample(t)) followed by wc.com_ref[:] = self.com_ref(t).  t_device: a one-element
+        tensor of the path's dtype holding the time - read by the kernel instead of `t` (graph capture)."""
         import ctypes as C
         from . import _lib
         if not hasattr(self, "_side32"):
@@ -300,5 +301,5 @@ class WalkSchedule:
                                          p(wc.ncon) if self.td_latch is not None else None,
                                          p(wc.con_pairs) if self.td_latch is not None else None,
                                          p(self.td_latch) if self.td_latch is not None else None, float(self.td_fraction),
-                                         wc._stream())
+                                         p(t_device) if t_device is not None else None, wc._stream())
         _lib.check(wc._L, wc._h, rc, "tsidb_walk_update")
