@@ -676,6 +676,8 @@ int tsidb_set_params(tsidb_handle h, const double *params, int n_params) {
   GUARD_BEGIN
   if (!params || n_params != P_COUNT) throw std::string("params must hold TSIDB_P_COUNT doubles");
   h->params.assign(params, params + n_params);
+  // kernels in flight on any stream (the pipelined sim stage runs on a non-blocking side stream) read the model
+  // constants: wait for all of them before the constants are replaced.  A rare call (RobotConfig edits).
   HIP_OK(hipDeviceSynchronize());
   if (h->dtype == TSIDB_F64) upload_model<double>(h); else upload_model<float>(h);
   GUARD_END

@@ -27,7 +27,6 @@ constexpr int NV = 26;
 constexpr int NA = 20;
 constexpr int NB = 21;   // sim bodies (MuJoCo document order, world excluded)
 constexpr int NVAR = 50; // [dv(26); f_slot0(12); f_slot1(12)]
-constexpr int LDJ = 51;  // padded leading dimension of the 50x50 J factor in LDS
 constexpr int LDD = 51;  // leading dimension of the dynamics rows [M | -Jc^T]
 constexpr int LDF = 27;  // leading dimension of frame / CoM Jacobians
 constexpr int NOBS = 65;

@@ -115,6 +115,11 @@ __device__ __forceinline__ T chol26_solve(T (&a)[NV], T rhs, int lane, bool &spd
   return x;
 }
 
+// the dense variant out of line: it runs only when a robot<->robot contact couples two branches of the tree, and
+// inlined next to the sparse one it doubles the Newton loop's code for nothing
+template <typename T>
+__device__ __noinline__ T chol26_dense(T (&a)[NV], T rhs, int lane, bool &spd) { return chol26_solve<T, true>(a, rhs, lane, spd); }
+
 // out = M * x for the lane's dof (x in LDS)
 template <typename T> __device__ __forceinline__ T mulM(const SimLds<T> &L, const T *x, int lane) {
   T s = 0;
@@ -595,9 +600,7 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
     for (int i = 0; i < 3; i++) fl.t1[i] *= nn;
     cross3(fl.n, fl.t1, fl.t2);
   }
-  const T dt = m.opt[0], gz = m.opt[1], tol = m.opt[2];
-  const int maxiter = (int)m.opt[3], ls_iter = (int)m.opt[4];
-  const T ls_tol = m.opt[5];
+  const T gz = m.opt[1];
   const T INF = Eps<T>::inf;
   const T MINVAL = T(1e-15);
   const bool quirks = m.params[P_QUIRKS] != 0;
@@ -866,11 +869,11 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
   bool hh_cross = false; // some robot<->robot contact couples two branches of the tree (dense Newton Hessian)
 #ifndef TSIDB_NO_HH
   if (m.params[P_SELF_COLLISION] != 0) {
-    // bounding spheres of all bodies in the world (lane = body, whose placement is still in its registers)
-    if (lane < NB) {
+    // bounding spheres of all bodies in the world (lane = body)
+    if (lane < NB) { // (placements from LDS: keeping this lane's copy in registers across the floor search spills)
       T c[3];
-      mat3vec(Rb, m.rbound[lane], c);
-      L.scen[lane][0] = c[0] + pb[0]; L.scen[lane][1] = c[1] + pb[1]; L.scen[lane][2] = c[2] + pb[2];
+      mat3vec(L.R[lane], m.rbound[lane], c);
+      L.scen[lane][0] = c[0] + L.p[lane][0]; L.scen[lane][1] = c[1] + L.p[lane][1]; L.scen[lane][2] = c[2] + L.p[lane][2];
       L.scen[lane][3] = m.rbound[lane][3];
     }
     __syncthreads();
@@ -926,6 +929,10 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
   // ---- constraint rows: frictionloss (lane = dof), pyramidal contact rows (lane = contact)
   // friction: floor contacts take the per-env value (config 5), robot<->robot contacts the model's
   const T mu = (lane >= nfl || !envp) ? m.contact[0] : envp[1];
+  // (solver constants are read where they are used: wave-uniform values held from the top of the kernel cost SGPRs,
+  //  and SGPRs spilled to VGPR lanes are what pushes this kernel over its VGPR budget)
+  asm volatile("" ::: "memory");
+  const T dt = m.opt[0];
   const T timeconst = m.contact[1] > 2 * dt ? m.contact[1] : 2 * dt, dampratio = m.contact[2];
   const T dmin = m.contact[3], dmax = m.contact[4], width = m.contact[5], mid = m.contact[6], power = m.contact[7];
   const T kk = T(1) / (dmax * dmax * timeconst * timeconst * dampratio * dampratio), bb = T(2) / (dmax * timeconst);
@@ -1014,6 +1021,9 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
     }
 
     TSIDB_STAMP(20);
+    asm volatile("" ::: "memory");
+    const T tol = m.opt[2], ls_tol = m.opt[5];
+    const int maxiter = (int)m.opt[3], ls_iter = (int)m.opt[4];
     const T scale = T(1) / (m.meaninertia * NV);
     T cost = 0;
     int iter = 0;
@@ -1190,7 +1200,15 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
 #pragma unroll
       for (int j = 0; j < NV; j++) arow[j] = lane < NV ? L.H[lane * LDM + j] : T(0);
       bool ok;
-      const T search = -(hh_cross ? chol26_solve<T, true>(arow, grad, lane, ok) : chol26_solve<T, false>(arow, grad, lane, ok));
+      T search;
+      if (hh_cross) { // rare: the out-of-line dense variant works on a copy, so that `arow` itself never leaves the registers
+        T dense_rows[NV];
+#pragma unroll
+        for (int j = 0; j < NV; j++) dense_rows[j] = arow[j];
+        search = -chol26_dense(dense_rows, grad, lane, ok);
+      } else {
+        search = -chol26_solve<T, false>(arow, grad, lane, ok);
+      }
       if (!ok) { fail |= 2; break; }
       TSIDB_LAP(26);
       // ---- exact line search along `search`
@@ -1236,24 +1254,26 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
   __syncthreads();
   TSIDB_STAMP(21);
   // ---- semi-implicit Euler, write back
+  asm volatile("" ::: "memory");
+  const T dte = m.opt[0];
   if (lane < NV) {
-    const T vn = L.qvel[lane] + dt * qacc;
+    const T vn = L.qvel[lane] + dte * qacc;
     L.qvel[lane] = vn;
     qvel_g[lane] = vn;
     qacc_ws_g[lane] = qacc;
     if (qacc_out) qacc_out[lane] = qacc;
   }
   __syncthreads();
-  if (lane < 3) L.qpos[lane] += dt * L.qvel[lane];
-  if (lane >= 6 && lane < NV) L.qpos[lane + 1] += dt * L.qvel[lane];
+  if (lane < 3) L.qpos[lane] += dte * L.qvel[lane];
+  if (lane >= 6 && lane < NV) L.qpos[lane + 1] += dte * L.qvel[lane];
   if (lane == 3) {
     const T *w = &L.qvel[3];
-    const T th = sqrt(dot3(w, w)) * dt;
+    const T th = sqrt(dot3(w, w)) * dte;
     T dq[4] = {1, 0, 0, 0};
     if (th > 0) {
       T sh, ch;
       sincos_t(T(0.5) * th, sh, ch);
-      const T s = sh * dt / th;
+      const T s = sh * dte / th;
       dq[0] = ch; dq[1] = s * w[0]; dq[2] = s * w[1]; dq[3] = s * w[2];
     }
     const T a[4] = {L.qpos[3], L.qpos[4], L.qpos[5], L.qpos[6]};

@@ -10,8 +10,9 @@
 // the base origin (no per-joint frame changes; keeps magnitudes < 0.5 m for fp32).  The 26x26
 // Hessian block is assembled, Cholesky-factorised and inverted entirely in registers with
 // v_readlane broadcasts (lane i owns row i); the force blocks' factor is a model constant.  The
-// dual active-set iterations keep J (50x51) and packed R in LDS; constraint adds use one Householder
-// reflection instead of eiquadprog's Givens chain (same iterates, no sequential sqrt/div chain).
+// dual active-set iterations keep J in registers too (lane i = row i, fixed column slots); only the small
+// triangular factor of the active inequality normals, row values and flags are in LDS; constraint adds use one
+// Householder reflection instead of eiquadprog's Givens chain (same iterates, no sequential sqrt/div chain).
 #pragma once
 #include "tsidb_common.hpp"
 
