@@ -778,17 +778,10 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
   } else if (lane >= 32 && lane < 38) L.xv[lane - 32] = 0;
   __syncthreads();
   if (lane < NV) qfs += L.xv[lane];
-  TSIDB_STAMP(17);
-  // ---- qacc_smooth = M^-1 qfrc_smooth
-  T arow[NV];
-#pragma unroll
-  for (int j = 0; j < NV; j++) arow[j] = lane < NV ? L.M[lane * LDM + j] : T(0);
-  bool spd;
-  const T qas = chol26_solve<T, false>(arow, qfs, lane, spd);
-  int fail = spd ? 0 : 1;
-
-  TSIDB_STAMP(18);
-  // ---- collision: floor (plane n.x = d, nominal z = 0, optionally with terrain steps) against each body's hull
+  // ---- floor collision, first half: bounding-sphere pretest for all bodies at once (lane = body, whose rotation and
+  //      position are still in this lane's registers).  Done BEFORE the factorisation below so that the placement
+  //      registers are dead during it (they were what spilled there); only the bodies that can reach the floor
+  //      enter the support search later, in body order
   const T margin = 0, tie_tol = m.opt[6];
   const T Ow[3] = {L.qpos[0], L.qpos[1], L.qpos[2]};
   const T nO = dot3(fl.n, Ow) - fl.d; // signed distance of the base origin O to the floor plane
@@ -798,15 +791,10 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
   const bool has_terr = terr_g != nullptr;
 #endif
   T hmax_all = 0;
-  if (has_terr) { // the tree-pass scratch is dead: stage this env's terrain table over it
-    if (lane < 20) L.terr[lane] = terr_g[lane];
-    __syncthreads();
+  if (has_terr) {
 #pragma unroll
-    for (int i = 0; i < 16; i++) hmax_all = L.terr[4 + i] > hmax_all ? L.terr[4 + i] : hmax_all;
+    for (int i = 0; i < 16; i++) hmax_all = terr_g[4 + i] > hmax_all ? terr_g[4 + i] : hmax_all;
   }
-  int ncon = 0;
-  // bounding-sphere pretest for all bodies at once (lane = body, whose rotation and position are still in
-  // this lane's registers); only the bodies that can reach the floor enter the support search, in body order
   unsigned long long cand_bodies;
   {
     bool near = false;
@@ -820,6 +808,26 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
     }
     cand_bodies = __ballot(near);
   }
+  TSIDB_STAMP(17);
+  // ---- qacc_smooth = M^-1 qfrc_smooth
+  T arow[NV];
+#pragma unroll
+  for (int j = 0; j < NV; j++) arow[j] = lane < NV ? L.M[lane * LDM + j] : T(0);
+  bool spd;
+  T qas = chol26_solve<T, false>(arow, qfs, lane, spd);
+  int fail = spd ? 0 : 1;
+  // park the two per-lane values that live across the collision phase in LDS (the contact-force scratch is free until
+  // the Newton loop): left in registers they are what the compiler spills to scratch around the narrow phase
+  T *park = &L.cfv[0][0];
+  if (lane < NV) { park[lane] = qas; park[NV + lane] = qfs; }
+
+  TSIDB_STAMP(18);
+  // ---- collision: floor (plane n.x = d, nominal z = 0, optionally with terrain steps) against each body's hull
+  if (has_terr) { // the tree-pass scratch is dead: stage this env's terrain table over it
+    if (lane < 20) L.terr[lane] = terr_g[lane];
+    __syncthreads();
+  }
+  int ncon = 0;
   for (unsigned long long bm = cand_bodies; bm && ncon < MAXCON; bm &= bm - 1) {
     const int b = __ffsll((long long)bm) - 1;
     const T *Rb = L.R[b];
@@ -922,6 +930,9 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
   }
 #endif
   __syncthreads();
+  qas = lane < NV ? park[lane] : T(0);
+  qfs = lane < NV ? park[NV + lane] : T(0);
+  asm volatile("" ::"v"(qas), "v"(qfs)); // (the reload is the definition the rest of the kernel uses)
   if (lane == 0 && ncon_out) ncon_out[0] = ncon;
   if (con_out && lane < MAXCON) con_out[lane] = lane < ncon ? ((L.cbody[lane] << 16) | L.cvert[lane]) : -1;
 
@@ -1151,7 +1162,7 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
           for (int j = 0; j < 6; j++) s += L.K[bk][sym_idx(i, j)] * L.S[k][j];
           G[i] = s;
         }
-        for (unsigned mk = dofanc; mk; mk &= mk - 1) {
+        for (unsigned mk = L.anc[lane < 6 ? 0 : lane - 5]; mk; mk &= mk - 1) { // (from LDS: the register copy would be spilled)
           const int a = __ffs(mk) - 1;
           const int i0 = a == 0 ? 0 : 5 + a, i1 = a == 0 ? 5 : 5 + a;
           for (int i = i0; i <= i1; i++) {
