@@ -1,7 +1,7 @@
 """GPU parity: the HIP path (through the C-ABI, via the WalkController facade) against the CPU oracle
 on the same seeded inputs.  Tolerances:
   f64 path  - tau/dv/f-wrench 1e-7 abs, next q/v/qpos 1e-9, qvel 1e-6; status, contact pairs bit-exact
-  f32 path  - tau, dv, per-foot wrench rtol 1e-3 / atol 2e-3 on one tick from identical inputs
+  f32 path  - tau, dv rtol 1e-3 / atol 1e-4, per-foot wrench rtol 1e-3 / atol 1e-3 on one tick from identical inputs
 The oracle itself is unpinned against tsid/pinocchio/mujoco (none available)."""
 import numpy as np
 import pytest
@@ -136,9 +136,12 @@ def test_single_tick_f32_within_tolerance(oracle):
         st["tau"][e], st["dv"][e], st["f"][e], st["status"][e] = out["tau"], out["dv"], out["f"], out["status"]
     assert np.array_equal(wc.status.cpu().numpy(), st["status"])
     tau, dv = wc.tau.double().cpu().numpy(), wc.dv.double().cpu().numpy()
-    assert np.allclose(tau, st["tau"], rtol=1e-3, atol=2e-3)
-    assert np.allclose(dv, st["dv"], rtol=1e-3, atol=2e-3)
-    assert np.allclose(wrench(wc.f.double().cpu().numpy(), wc.params), wrench(st["f"], wc.params), rtol=1e-3, atol=2e-3)
+    # rtol 1e-3, atol 1e-4 (observed: tau 8e-5 abs, dv 2e-5 abs).  The per-foot wrench meets the
+    # relative part only with atol 1e-3 (observed 9.7e-4 on 20 N components: the regularised force split is the
+    # worst-conditioned output of the QP)
+    assert np.allclose(tau, st["tau"], rtol=1e-3, atol=1e-4)
+    assert np.allclose(dv, st["dv"], rtol=1e-3, atol=1e-4)
+    assert np.allclose(wrench(wc.f.double().cpu().numpy(), wc.params), wrench(st["f"], wc.params), rtol=1e-3, atol=1e-3)
     assert diff(wc.q, st["q"]) < 1e-5 and diff(wc.v, st["v"]) < 1e-4
 
 
