@@ -144,6 +144,11 @@ int tsidb_walk_update(tsidb_handle h, const void *coef, const int32_t *side, con
 int tsidb_rbd_terms(tsidb_handle h, const void *q, const void *v, void *M, void *hbias, void *Jcom, void *Jf,
                     void *oMf, void *com, void *stream);
 
+/* dimensions of the robot this library was built for (one library per robot: libtsidb.so = the v1 robot of ctrl/conf.py:9-15,
+ * libtsidb_v0.so = robot/v0, TSID side only): out6 = NJ, NQ, NV, NA, sim bodies, 1 if the sim stage is built.  The TSIDB_N*
+ * constants above are the v1 robot's. */
+int tsidb_dims(int *out6);
+
 /* bytes of LDS one env occupies in kernel `which` (0 tick, 1 sim) for `dtype` */
 int tsidb_lds_bytes(int dtype, int which);
 

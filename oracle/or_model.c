@@ -40,6 +40,12 @@ static int geti(const uint8_t *b, const char *name, int *dst, uint32_t cnt) {
   return 0;
 }
 
+int or_dims(int *out6) {
+  const int d[6] = {OR_NJ, OR_NQ, OR_NV, OR_NA, OR_NB, OR_HAS_SIM};
+  for (int i = 0; i < 6; i++) out6[i] = d[i];
+  return 0;
+}
+
 OrModel *or_model_load(const void *blob, size_t nbytes) {
   if (nbytes < 16 || memcmp(blob, "TSIDBM01", 8) != 0) return NULL;
   uint8_t *b = (uint8_t *)malloc(nbytes);
@@ -55,6 +61,19 @@ OrModel *or_model_load(const void *blob, size_t nbytes) {
   e |= getf(b, "pin_effort", m->effort, OR_NA);
   e |= getf(b, "pin_velocity", m->velocity, OR_NA);
   e |= getf(b, "pin_q0", m->q0, OR_NQ);
+  {
+    int md[6] = {0};
+    if (geti(b, "model_dims", md, 6) || md[0] != OR_NJ || md[3] != OR_NA || md[5] != OR_HAS_SIM) {
+      fprintf(stderr, "oracle: the blob is for another robot than this build\n");
+      e |= -1;
+    }
+  }
+  if (!OR_HAS_SIM) { /* TSID-only robot: no sim sections */
+    if (e) { or_model_free(m); return NULL; }
+    m->floss_scale = 1.0;
+    m->foot_body[0] = m->foot_body[1] = -1;
+    return m;
+  }
   e |= geti(b, "mj_parent", m->mj_parent, OR_NB);
   e |= getf(b, "mj_pos", &m->mj_pos[0][0], OR_NB * 3);
   e |= getf(b, "mj_quat", &m->mj_quat[0][0], OR_NB * 4);

@@ -584,10 +584,10 @@ int or_tsid_tick_cop(const OrModel *m, const double *params, double *q, double *
       cop[0] = (copw[0][0] * fz[0] + copw[1][0] * fz[1]) / (fz[0] + fz[1]);
       cop[1] = (copw[0][1] * fz[0] + copw[1][1] * fz[1]) / (fz[0] + fz[1]);
     }
-    memcpy(obs + 53, t.com, 3 * sizeof(double));
-    memcpy(obs + 56, cop, 3 * sizeof(double));
-    memcpy(obs + 59, t.oMf[0] + 9, 3 * sizeof(double));
-    memcpy(obs + 62, t.oMf[1] + 9, 3 * sizeof(double));
+    memcpy(obs + OR_NQ + OR_NV, t.com, 3 * sizeof(double));
+    memcpy(obs + OR_NQ + OR_NV + 3, cop, 3 * sizeof(double));
+    memcpy(obs + OR_NQ + OR_NV + 6, t.oMf[0] + 9, 3 * sizeof(double));
+    memcpy(obs + OR_NQ + OR_NV + 9, t.oMf[1] + 9, 3 * sizeof(double));
   }
   if (status == 0) {
     /* integrate_dv: v_mean = v + dt/2 dv ; v += dt dv ; q = integrate(q, dt v_mean) */

@@ -18,9 +18,17 @@
 extern "C" {
 #endif
 
-enum { OR_NJ = 21, OR_NQ = 27, OR_NV = 26, OR_NA = 20, OR_NB = 21, OR_NF = 2 };
-enum { OR_NVAR = 50, OR_NEQ = 18, OR_NIN = 160 };
-enum { OR_MAXCON = 32, OR_MAXHH = 12 /* robot<->robot contacts per env */, OR_MAXEFC = 20 + 4 * OR_MAXCON, OR_NOBS = 65, OR_MAXPAIR = 256 };
+/* One library per robot, like libtsidb: liboracle.so = the v1 robot (ctrl/conf.py:9-15), liboracle_v0.so (-DOR_ROBOT_V0) =
+ * robot/v0, TSID side only (its MJCF needs sim features that are not built). */
+#ifdef OR_ROBOT_V0
+enum { OR_NJ = 19, OR_NQ = 25, OR_NV = 24, OR_NA = 18, OR_NB = 19, OR_NF = 2, OR_HAS_SIM = 0 };
+#else
+enum { OR_NJ = 21, OR_NQ = 27, OR_NV = 26, OR_NA = 20, OR_NB = 21, OR_NF = 2, OR_HAS_SIM = 1 };
+#endif
+enum { OR_NVAR = OR_NV + 24, OR_NEQ = 18, OR_NIN = 68 + 2 * OR_NA + 2 * OR_NV };
+enum { OR_MAXCON = 32, OR_MAXHH = 12 /* robot<->robot contacts per env */, OR_MAXEFC = OR_NA + 4 * OR_MAXCON,
+       OR_NOBS = OR_NQ + OR_NV + 12, OR_MAXPAIR = 256 };
+int or_dims(int *out6); /* NJ, NQ, NV, NA, sim bodies, has_sim of this build */
 
 /* parameter vector indices (RobotConfig values; ctrl/conf.py:21-72) */
 enum {

@@ -13,33 +13,42 @@ HERE = Path(__file__).parent
 NQ, NV, NA, NVAR, NEQ, NIN, MAXCON, MAXEFC, NOBS = 27, 26, 20, 50, 18, 160, 32, 20 + 4 * 32, 65
 
 
-class OrTerms(C.Structure):
-    _fields_ = [("M", C.c_double * (NV * NV)), ("h", C.c_double * NV), ("com", C.c_double * 3),
-                ("vcom", C.c_double * 3), ("acom", C.c_double * 3), ("Jcom", C.c_double * (3 * NV)),
-                ("oMf", C.c_double * 24), ("Jf", C.c_double * (2 * 6 * NV)), ("vf", C.c_double * 12),
-                ("af", C.c_double * 12), ("mass", C.c_double), ("Aam", C.c_double * (3 * NV)), ("Lam", C.c_double * 3),
-                ("dLam", C.c_double * 3)]
+def _structs(NQ, NV, NA):
+    """ctypes mirrors of oracle.h's structs for a robot's dimensions (one liboracle*.so per robot)"""
+    NVAR, NEQ, NIN, MAXEFC = NV + 24, 18, 68 + 2 * NA + 2 * NV, NA + 4 * MAXCON
+
+    class OrTerms(C.Structure):
+        _fields_ = [("M", C.c_double * (NV * NV)), ("h", C.c_double * NV), ("com", C.c_double * 3),
+                    ("vcom", C.c_double * 3), ("acom", C.c_double * 3), ("Jcom", C.c_double * (3 * NV)),
+                    ("oMf", C.c_double * 24), ("Jf", C.c_double * (2 * 6 * NV)), ("vf", C.c_double * 12),
+                    ("af", C.c_double * 12), ("mass", C.c_double), ("Aam", C.c_double * (3 * NV)), ("Lam", C.c_double * 3),
+                    ("dLam", C.c_double * 3)]
+
+    class OrQP(C.Structure):
+        _fields_ = [("nvar", C.c_int), ("neq", C.c_int), ("nin", C.c_int),
+                    ("H", C.c_double * (NVAR * NVAR)), ("g", C.c_double * NVAR),
+                    ("CE", C.c_double * (NEQ * NVAR)), ("ce0", C.c_double * NEQ),
+                    ("CI", C.c_double * (NIN * NVAR)), ("ci0", C.c_double * NIN), ("slot_foot", C.c_int * 2)]
+
+    class OrQPSol(C.Structure):
+        _fields_ = [("x", C.c_double * NVAR), ("u", C.c_double * (NEQ + NIN)), ("A", C.c_int * (NEQ + NIN)),
+                    ("iq", C.c_int), ("iter", C.c_int), ("status", C.c_int), ("f_value", C.c_double)]
+
+    class OrSimInfo(C.Structure):
+        _fields_ = [("ncon", C.c_int), ("nefc", C.c_int), ("solver_iter", C.c_int),
+                    ("con_geom", C.c_int * MAXCON), ("con_vert", C.c_int * MAXCON),
+                    ("con_dist", C.c_double * MAXCON), ("con_pos", C.c_double * (3 * MAXCON)),
+                    ("efc_force", C.c_double * MAXEFC), ("qacc", C.c_double * NV), ("qacc_smooth", C.c_double * NV),
+                    ("qfrc_bias", C.c_double * NV), ("qfrc_actuator", C.c_double * NV), ("M", C.c_double * (NV * NV)),
+                    ("con_body1", C.c_int * MAXCON), ("con_frame", C.c_double * (3 * MAXCON)), ("flags", C.c_int)]
+
+    import types
+    return types.SimpleNamespace(OrTerms=OrTerms, OrQP=OrQP, OrQPSol=OrQPSol, OrSimInfo=OrSimInfo, NQ=NQ, NV=NV, NA=NA,
+                                 NVAR=NVAR, NEQ=NEQ, NIN=NIN, MAXEFC=MAXEFC, NOBS=NQ + NV + 12)
 
 
-class OrQP(C.Structure):
-    _fields_ = [("nvar", C.c_int), ("neq", C.c_int), ("nin", C.c_int),
-                ("H", C.c_double * (NVAR * NVAR)), ("g", C.c_double * NVAR),
-                ("CE", C.c_double * (NEQ * NVAR)), ("ce0", C.c_double * NEQ),
-                ("CI", C.c_double * (NIN * NVAR)), ("ci0", C.c_double * NIN), ("slot_foot", C.c_int * 2)]
-
-
-class OrQPSol(C.Structure):
-    _fields_ = [("x", C.c_double * NVAR), ("u", C.c_double * (NEQ + NIN)), ("A", C.c_int * (NEQ + NIN)),
-                ("iq", C.c_int), ("iter", C.c_int), ("status", C.c_int), ("f_value", C.c_double)]
-
-
-class OrSimInfo(C.Structure):
-    _fields_ = [("ncon", C.c_int), ("nefc", C.c_int), ("solver_iter", C.c_int),
-                ("con_geom", C.c_int * MAXCON), ("con_vert", C.c_int * MAXCON),
-                ("con_dist", C.c_double * MAXCON), ("con_pos", C.c_double * (3 * MAXCON)),
-                ("efc_force", C.c_double * MAXEFC), ("qacc", C.c_double * NV), ("qacc_smooth", C.c_double * NV),
-                ("qfrc_bias", C.c_double * NV), ("qfrc_actuator", C.c_double * NV), ("M", C.c_double * (NV * NV)),
-                ("con_body1", C.c_int * MAXCON), ("con_frame", C.c_double * (3 * MAXCON)), ("flags", C.c_int)]
+_V1 = _structs(NQ, NV, NA)
+OrTerms, OrQP, OrQPSol, OrSimInfo = _V1.OrTerms, _V1.OrQP, _V1.OrQPSol, _V1.OrSimInfo
 
 
 class OrWalkTables(C.Structure):
@@ -74,10 +83,11 @@ class WalkTables:
 
 
 def build(force=False):
-    so = HERE / "liboracle.so"
+    so, so0 = HERE / "liboracle.so", HERE / "liboracle_v0.so"
     srcs = list(HERE.glob("*.c")) + [HERE / "oracle.h"]
-    if force or not so.exists() or any(s.stat().st_mtime > so.stat().st_mtime for s in srcs):
-        subprocess.run(["make", "-C", str(HERE), "liboracle.so"], check=True, capture_output=True)
+    for lib in (so, so0):
+        if force or not lib.exists() or any(s.stat().st_mtime > lib.stat().st_mtime for s in srcs):
+            subprocess.run(["make", "-C", str(HERE), lib.name], check=True, capture_output=True)
     return so
 
 
@@ -92,10 +102,23 @@ def _f64(a):
 class Oracle:
     def __init__(self, blob_bytes: bytes, lib_path=None):
         import os
-        so = Path(lib_path or os.environ.get("TSIDB_ORACLE_LIB") or HERE / "liboracle.so")  # env: sanitizer build
+        import struct
+        # which robot is the blob for?  (model_dims section: NJ NQ NV NA NB has_sim) -> liboracle.so or liboracle_v0.so
+        nsec = struct.unpack_from("<I", blob_bytes, 8)[0]
+        md = None
+        for i in range(nsec):
+            off = 16 + 40 * i
+            if blob_bytes[off:off + 24].split(b"\0")[0] == b"model_dims":
+                _, cnt, o = struct.unpack_from("<IIQ", blob_bytes, off + 24)
+                md = struct.unpack_from("<6i", blob_bytes, o)
+        if md is None:
+            raise RuntimeError("oracle: the blob has no model_dims section")
+        default = HERE / ("liboracle.so" if md[5] else "liboracle_v0.so")
+        so = Path(lib_path or (os.environ.get("TSIDB_ORACLE_LIB") if md[5] else None) or default)  # env: sanitizer build (v1)
         if not so.exists():
-            so = build()
+            build()
         self.lib = L = C.CDLL(str(so))
+        self.S = _structs(md[1], md[2], md[3])
         L.or_model_load.restype = C.c_void_p
         L.or_model_load.argtypes = [C.c_char_p, C.c_size_t]
         for name in ("or_model_free", "or_rbd_terms", "or_rnea", "or_integrate", "or_log6", "or_tsid_assemble", "or_walk_update"):
@@ -115,7 +138,8 @@ class Oracle:
 
     # ---- rigid-body terms
     def terms(self, q, v):
-        t = OrTerms()
+        S = self.S; NV = S.NV
+        t = S.OrTerms()
         q, v = _f64(q), _f64(v)
         self.lib.or_rbd_terms(self.m, _p(q), _p(v), C.byref(t))
         g = lambda f, *s: np.array(f, dtype=np.float64).reshape(*s)
@@ -125,13 +149,13 @@ class Oracle:
 
     def rnea(self, q, v, a):
         q, v, a = _f64(q), _f64(v), _f64(a)
-        tau = np.zeros(NV)
+        tau = np.zeros(self.S.NV)
         self.lib.or_rnea(self.m, _p(q), _p(v), _p(a), _p(tau))
         return tau
 
     def integrate(self, q, vdt):
         q, vdt = _f64(q), _f64(vdt)
-        out = np.zeros(NQ)
+        out = np.zeros(self.S.NQ)
         self.lib.or_integrate(_p(q), _p(vdt), _p(out))
         return out
 
@@ -144,7 +168,8 @@ class Oracle:
     # ---- TSID problem
     def assemble(self, params, q, v, com_ref, posture_ref, foot_ref, contact_ref, contact_active, cop_ref=None):
         t = self.terms(q, v)["_raw"]
-        qp = OrQP()
+        S = self.S; NVAR, NEQ, NIN = S.NVAR, S.NEQ, S.NIN
+        qp = S.OrQP()
         a = [_f64(x) for x in (params, q, v, com_ref, posture_ref, foot_ref, contact_ref)]
         ca = np.ascontiguousarray(contact_active, dtype=np.uint8)
         cr = _f64(cop_ref) if cop_ref is not None else None
@@ -159,7 +184,7 @@ class Oracle:
                     slot_foot=list(qp.slot_foot), _raw=qp)
 
     def qp_solve(self, qp_raw, max_iter=1000):
-        sol = OrQPSol()
+        sol = self.S.OrQPSol()
         st = self.lib.or_qp_solve(C.byref(qp_raw), max_iter, C.byref(sol))
         n = qp_raw.nvar
         return dict(status=st, x=np.array(sol.x)[:n], u=np.array(sol.u)[:sol.iq], A=np.array(sol.A)[:sol.iq],
@@ -171,7 +196,8 @@ class Oracle:
         a = [_f64(x) for x in (params, com_ref, posture_ref, foot_ref, contact_ref)]
         ca = np.ascontiguousarray(contact_active, dtype=np.uint8)
         cf = _f64(cop_frames) if cop_frames is not None else None
-        tau, dv, f, obs = np.zeros(NA), np.zeros(NV), np.zeros(24), np.zeros(NOBS)
+        S = self.S
+        tau, dv, f, obs = np.zeros(S.NA), np.zeros(S.NV), np.zeros(24), np.zeros(S.NOBS)
         it = C.c_int(0)
         cr = _f64(cop_ref) if cop_ref is not None else None
         self.lib.or_tsid_tick_cop.restype = C.c_int
@@ -184,7 +210,8 @@ class Oracle:
     def sim_step(self, qpos, qvel, ctrl, qacc_ws, envp=None, terrain=None, self_collision=True):
         assert all(x.dtype == np.float64 for x in (qpos, qvel, qacc_ws))
         ctrl = _f64(ctrl)
-        info = OrSimInfo()
+        info = self.S.OrSimInfo()
+        NV = self.S.NV
         ep = _f64(envp) if envp is not None else None
         tr = _f64(terrain) if terrain is not None else None
         self.lib.or_sim_step_ext.restype = C.c_int
@@ -250,8 +277,11 @@ def walk_update(lib, sched, t, frames, foot_ref, contact_ref, contact_active, co
                        _p(contact_active), _p(com_ref))
 
 
-def new_state(n):
-    """Zeroed env-major float64 state/IO arrays in the layout or_env_step_batch expects."""
+def new_state(n, dims=None):
+    """Zeroed env-major float64 state/IO arrays in the layout or_env_step_batch expects (dims = (NQ, NV, NA) of the
+    robot; default the v1 robot's)."""
+    NQ, NV, NA = dims if dims is not None else (_V1.NQ, _V1.NV, _V1.NA)
+    NOBS = NQ + NV + 12
     z = lambda *s: np.zeros(s, dtype=np.float64)
     return dict(q=z(n, NQ), v=z(n, NV), qpos=z(n, NQ), qvel=z(n, NV), qacc_ws=z(n, NV), com_ref=z(n, 9),
                 posture_ref=z(n, NA), foot_ref=z(n, 2, 24), contact_ref=z(n, 2, 12),

@@ -9,25 +9,46 @@ import os
 # TSIDB_LIB_PATH selects a diagnostic build (tools/stamp_profile.py); the product default is in-tree
 LIB_PATH = Path(os.environ.get("TSIDB_LIB_PATH", _HERE / "libtsidb.so"))
 
-SYMBOLS = ["tsidb_create", "tsidb_destroy", "tsidb_last_error", "tsidb_set_params", "tsidb_set_refs", "tsidb_reset",
+SYMBOLS = ["tsidb_dims", "tsidb_create", "tsidb_destroy", "tsidb_last_error", "tsidb_set_params", "tsidb_set_refs", "tsidb_reset",
            "tsidb_tick", "tsidb_sim", "tsidb_step", "tsidb_rbd_terms", "tsidb_lds_bytes", "tsidb_walk_update", "tsidb_set_env_params", "tsidb_set_cop_ref"]
 
-_lib = None
+_libs = {}
 
 
 class TsidbError(RuntimeError):
     pass
 
 
-def load():
-    """Load libtsidb.so once; raise loudly when it has not been built (python __graft_entry__.py build)."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not LIB_PATH.exists():
-        raise TsidbError(f"{LIB_PATH} is missing: build the HIP extension first "
+def dims(L):
+    """(NJ, NQ, NV, NA, sim bodies, has_sim) of the robot a loaded library was built for"""
+    out = (C.c_int * 6)()
+    L.tsidb_dims(out)
+    return tuple(out)
+
+
+def load_for(model_dims):
+    """The library built for a blob's robot (its model_dims section): one libtsidb*.so per robot sits next to this file
+    (libtsidb.so = the v1 robot, libtsidb_v0.so = robot/v0).  TSIDB_LIB_PATH (diagnostic builds) is tried first."""
+    want = tuple(int(x) for x in model_dims)
+    cands = [LIB_PATH] + sorted(p for p in _HERE.glob("libtsidb*.so") if p != LIB_PATH)
+    for p in cands:
+        if p.exists():
+            L = load(p)
+            if dims(L) == want:
+                return L
+    raise TsidbError(f"no libtsidb*.so in {_HERE} is built for a robot with dimensions {want}: compile the blob's topology "
+                     "header into a library (python -c 'import __graft_entry__ as g; g.build()')")
+
+
+def load(path=None):
+    """Load a libtsidb*.so once (default: libtsidb.so, the v1 robot); raise loudly when it has not been built."""
+    path = Path(path) if path is not None else LIB_PATH
+    if path in _libs:
+        return _libs[path]
+    if not path.exists():
+        raise TsidbError(f"{path} is missing: build the HIP extension first "
                          "(python -c 'import __graft_entry__ as g; g.build()'); there is no CPU path")
-    L = C.CDLL(str(LIB_PATH))
+    L = C.CDLL(str(path))
     vp, i32p = C.c_void_p, C.c_void_p
     L.tsidb_create.argtypes = [vp, C.c_size_t, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
     L.tsidb_destroy.argtypes = [vp]
@@ -44,10 +65,11 @@ def load():
     L.tsidb_set_env_params.argtypes = [vp, vp, vp]
     L.tsidb_set_cop_ref.argtypes = [vp, vp]
     L.tsidb_walk_update.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int] + [C.c_double] * 6 + [vp, vp, vp, vp, vp, C.c_double, vp, vp]
+    L.tsidb_dims.argtypes = [C.POINTER(C.c_int)]
     for s in SYMBOLS:
         if s != "tsidb_last_error":
             getattr(L, s).restype = C.c_int
-    _lib = L
+    _libs[path] = L
     return L
 
 

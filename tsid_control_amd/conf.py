@@ -103,3 +103,30 @@ class RobotConfig:
     reward_torque_cost = 1e-3
     done_base_height = 0.2     # done = failed QP, base lower than this [m], or tilted by more than done_tilt_deg
     done_tilt_deg = 45.0
+
+
+def op3_v0_conf() -> RobotConfig:
+    """The v0 robot (robot/v0/robot.urdf + robot.srdf: 18 actuated joints, no ankle roll) with the values of its own
+    configuration, legacy/op3_conf.py:11-62 - SURVEY.md 8f-4.  Only its TSID side is compiled (assets/op3_v0.tsidb,
+    libtsidb_v0.so): its MJCF (robot/v0/robot.xml:2-9) needs sim features outside the built subset, so sim_enabled is
+    off.  The stack is this package's (ctrl/WalkController.py's): the joint-bound rows stay in even though
+    legacy/op3_conf.py:21 switches them off (w_joint_bounds = 0; at +-10 x the velocity limit they never activate)."""
+    from pathlib import Path
+    c = RobotConfig()
+    c.model_blob = str(Path(__file__).parent / "assets" / "op3_v0.tsidb")
+    c.robot_path, c.urdf, c.srdf, c.mjcf = "./robot", "./robot/robot.urdf", "./robot/robot.srdf", "./robot/robot.xml"   # op3_conf.py:56-62
+    c.lf_fixed_joint, c.rf_fixed_joint = "leg_left_sole_joint_fixed", "leg_right_sole_joint_fixed"            # op3_conf.py:53-54
+    c.step_length, c.step_height, c.step_width, c.step_duration = 0.1, 0.05, 0.1275, 0.7                         # op3_conf.py:8-11
+    c.w_com, c.w_am, c.w_foot, c.w_posture, c.w_forceRef, c.w_cop = 1.0, 1e-3, 1e-1, 1e-1, 1e-5, 0.0               # op3_conf.py:13-20
+    c.w_torque_bounds = 1e-1
+    c.lxp = c.lxn = 0.0275                                                                                       # op3_conf.py:23-27
+    c.lyp = c.lyn = 0.055
+    c.mu, c.fMin, c.fMax = 0.5, 0.0, 1000.0
+    c.tau_max_scaling, c.v_max_scaling = 3.0, 10.0                                                               # op3_conf.py:33-34
+    c.kp_contact = c.kp_foot = c.kp_com = c.kp_am = 10.0
+    c.kp_posture = 1.0
+    c.masks_posture = np.ones(18)
+    c.gain_vector = np.array([100.0, 100.0, 10.0, 5.0, 5.0, 1.0, 1.0, 10.0, 10.0, 10.0,
+                              10.0, 5.0, 5.0, 1.0, 1.0, 10.0, 10.0, 10.0])                                         # op3_conf.py:42-48
+    c.sim_enabled = False
+    return c

@@ -3,7 +3,6 @@
 #include "tsidb_common.hpp"
 #include "tsidb_sim.hpp"
 #include "tsidb_tick.hpp"
-#include "tsidb_topology.hpp"
 
 #include <cmath>
 #include <cstdio>
@@ -488,7 +487,8 @@ static void build_model(tsidb_ctx *h, DevModel<T> &m) {
     m.Hf_trace = (T)tr;
     m.Jf0_trace = (T)trJ;
   }
-  // ---- sim side
+  // ---- sim side (absent in a TSID-only build)
+  if constexpr (!TOPO_HAS_SIM) return;
   memcpy(m.mj_parent, b.i32("mj_parent", NB), sizeof m.mj_parent);
   for (int j = 0; j < NB; j++)
     if (m.mj_parent[j] != TOPO_PARENT[j])
@@ -551,7 +551,8 @@ static void build_model(tsidb_ctx *h, DevModel<T> &m) {
 template <typename T>
 static void upload_model(tsidb_ctx *h) {
   const Blob &b = h->blob;
-  if (!h->d_hull) {
+  if (!h->d_model && !TOPO_HAS_SIM) HIP_OK(hipMalloc(&h->d_model, sizeof(DevModel<T>)));
+  if (!h->d_hull && TOPO_HAS_SIM) {
     const uint32_t nvert3 = b.count("mj_hull_vert"), nedge = b.count("mj_hull_edge"), neadr = b.count("mj_hull_eadr");
     const double *hv = b.f64("mj_hull_vert", 0);
     std::vector<T> hvt(nvert3);
@@ -619,6 +620,8 @@ static void launch_tick(tsidb_ctx *h, void *q, void *v, void *tau, void *dv, voi
 template <typename T>
 static void launch_sim(tsidb_ctx *h, const void *q_tsid, const void *v_tsid, void *qpos, void *qvel, void *qacc_ws, void *qacc,
                        int32_t *ncon, int32_t *con, int32_t *info, hipStream_t s, const void *motor_tau = nullptr) {
+  if constexpr (!TOPO_HAS_SIM) throw std::string("this library was built without the sim stage");
+  else
   hipLaunchKernelGGL(k_sim<T>, dim3(h->num_envs), dim3(WAVE), 0, s, (const DevModel<T> *)h->d_model, h->num_envs,
                      (const T *)q_tsid, (const T *)v_tsid, (T *)qpos, (T *)qvel, (T *)qacc_ws, (const T *)h->env_params, (const T *)h->terrain, (const T *)motor_tau, (T *)qacc, ncon, con, info);
   HIP_OK(hipGetLastError());
@@ -640,13 +643,22 @@ int tsidb_create(const void *model_blob, size_t nbytes, const double *params, in
     h->device = device; h->dtype = dtype; h->num_envs = num_envs;
     h->blob.raw.assign((const uint8_t *)model_blob, (const uint8_t *)model_blob + nbytes);
     h->blob.validate();
+    { // the blob must be for the robot this library was built for
+      const int want[6] = {NJ, NQ, NV, NA, NB, TOPO_HAS_SIM};
+      const int *got = h->blob.i32("model_dims", 6);
+      for (int i = 0; i < 6; i++)
+        if (got[i] != want[i])
+          throw std::string("model blob is for another robot than this library (dimensions differ: build the library with "
+                            "the blob's topology header, -DTSIDB_TOPOLOGY_HEADER)");
+    }
     h->params.assign(params, params + n_params);
+    if (!TOPO_HAS_SIM && h->params[P_SIM_ENABLED] != 0.0) throw std::string("this library was built without the sim stage: set sim_enabled = False");
     int ndev = 0;
     HIP_OK(hipGetDeviceCount(&ndev));
     if (device < 0 || device >= ndev) throw std::string("no such HIP device (this library has no CPU path)");
     HIP_OK(hipSetDevice(device));
     if (dtype == TSIDB_F64) upload_model<double>(h); else upload_model<float>(h);
-    { // sim body of each sole frame: frame -> TSID joint -> sim joint (mj_sim2tsid) -> body
+    if (TOPO_HAS_SIM) { // sim body of each sole frame: frame -> TSID joint -> sim joint (mj_sim2tsid) -> body
       const int *fp = h->blob.i32("pin_frame_parent", 2), *s2t = h->blob.i32("mj_sim2tsid", NA);
       for (int f = 0; f < 2; f++)
         for (int i = 0; i < NA; i++)
@@ -813,6 +825,14 @@ int tsidb_debug_stamps(unsigned long long *out, int n) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamp), sizeof(unsigned long long) * 32 * (size_t)n);
 }
 #endif
+
+/* dimensions of the robot this library was built for: NJ, NQ, NV, NA, NB (sim bodies), 1 if the sim stage is built */
+int tsidb_dims(int *out6) {
+  if (!out6) return -1;
+  const int d[6] = {NJ, NQ, NV, NA, NB, TOPO_HAS_SIM};
+  for (int i = 0; i < 6; i++) out6[i] = d[i];
+  return 0;
+}
 
 int tsidb_lds_bytes(int dtype, int which) {
   if (dtype == TSIDB_F64) return which == 0 ? (int)sizeof(TickLds<double>) : (int)sizeof(SimLds<double>);

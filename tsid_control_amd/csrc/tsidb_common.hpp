@@ -19,18 +19,26 @@ __device__ unsigned long long g_stamp[8192][32];
 #define TSIDB_LAP_ZERO(k) do { } while (0)
 #endif
 
+// One library is built per robot: the generated header (model_compiler.py) carries its dimensions and sim tree.
+#ifndef TSIDB_TOPOLOGY_HEADER
+#define TSIDB_TOPOLOGY_HEADER "tsidb_topology.hpp"
+#endif
+#include TSIDB_TOPOLOGY_HEADER
+
 namespace tsidb {
 
-constexpr int NJ = 21;   // TSID joints incl. the free-flyer root (pinocchio order)
-constexpr int NQ = 27;
-constexpr int NV = 26;
-constexpr int NA = 20;
-constexpr int NB = 21;   // sim bodies (MuJoCo document order, world excluded)
-constexpr int NVAR = 50; // [dv(26); f_slot0(12); f_slot1(12)]
-constexpr int LDD = 51;  // leading dimension of the dynamics rows [M | -Jc^T]
-constexpr int LDF = 27;  // leading dimension of frame / CoM Jacobians
-constexpr int NOBS = 65;
-constexpr int NROW = 67; // obs row + reward + done when the caller's row stride has room for them
+constexpr int NJ = TOPO_NJ;   // TSID joints incl. the free-flyer root (pinocchio order); 21 for the v1 robot
+constexpr int NQ = TOPO_NQ;   // 27
+constexpr int NV = TOPO_NV;   // 26
+constexpr int NA = TOPO_NA;   // 20
+constexpr int NB = TOPO_NB;   // sim bodies (MuJoCo document order, world excluded); 21
+constexpr int NVAR = NV + 24; // [dv(NV); f_slot0(12); f_slot1(12)]; 50
+constexpr int LDD = NVAR + 1; // leading dimension of the dynamics rows [M | -Jc^T]
+constexpr int LDF = NV + 1;   // leading dimension of frame / CoM Jacobians
+constexpr int NOBS = NQ + NV + 12; // q, v, com, cop, LF, RF; 65
+constexpr int NROW = NOBS + 2;     // obs row + reward + done when the caller's row stride has room for them
+static_assert(NJ == NV - 5 && NQ == NV + 1 && NA == NV - 6, "one free-flyer + hinges");
+static_assert(NJ <= 32 && NB <= 32 && NVAR <= 64 && NA <= 20 && 32 + NA <= 64, "lane / bitmask / parameter-vector limits");
 constexpr int MAXCON = 32;
 constexpr int MAXHH = 12;    // robot<->robot contacts per env (the last slots of the contact list)
 constexpr int MAXPAIR = 192; // candidate body pairs (three rounds of one lane per pair)

@@ -14,7 +14,6 @@
 #pragma once
 #include "tsidb_common.hpp"
 #include "tsidb_tick.hpp" // rdlane
-#include "tsidb_topology.hpp"
 
 namespace tsidb {
 
@@ -990,7 +989,7 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
 
   int solver_iter = 0;
   T qacc = qas;
-  const int nefc = 20 + 4 * ncon; // frictionloss rows exist on all 20 hinges
+  const int nefc = NA + 4 * ncon; // frictionloss rows exist on all hinges
   if (nefc > 0) {
     // helpers over a candidate qacc held per lane (value `xa`, also staged in L.xv)
     auto stage = [&](T xa) { __syncthreads(); if (lane < NV) L.xv[lane] = xa; __syncthreads(); };

@@ -1161,11 +1161,11 @@ __device__ __forceinline__ void tsid_tick_env(const DevModel<T> &m, TickLds<T> &
         cop[1] = (copw[0][1] * fz[0] + copw[1][1] * fz[1]) / (fz[0] + fz[1]);
       }
 #pragma unroll
-      for (int i = 0; i < 3; i++) obs[56 + i] = cop[i];
+      for (int i = 0; i < 3; i++) obs[NQ + NV + 3 + i] = cop[i];
     }
-    if (lane >= 8 && lane < 11) obs[53 + lane - 8] = L.com[lane - 8];
-    if (lane >= 16 && lane < 19) obs[59 + lane - 16] = L.oMf[0][9 + lane - 16];
-    if (lane >= 24 && lane < 27) obs[62 + lane - 24] = L.oMf[1][9 + lane - 24];
+    if (lane >= 8 && lane < 11) obs[NQ + NV + lane - 8] = L.com[lane - 8];
+    if (lane >= 16 && lane < 19) obs[NQ + NV + 6 + lane - 16] = L.oMf[0][9 + lane - 16];
+    if (lane >= 24 && lane < 27) obs[NQ + NV + 9 + lane - 24] = L.oMf[1][9 + lane - 24];
   }
   // ---- integrate_dv (WalkController.py:291-295); a failed QP leaves the state untouched
   if (status == 0) {

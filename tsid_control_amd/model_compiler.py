@@ -452,6 +452,8 @@ def compile_model(ref_root: Path, out: Path):
              if bodies[j]["parent"] != i and bodies[i]["parent"] != j and (i, j) not in exc]
 
     sections = {
+        "model_dims": np.array([len(ts["names"]), len(ts["names"]) + 6, len(ts["names"]) + 5, len(ts["names"]) - 1, nb, 1],
+                               np.int32),  # NJ NQ NV NA NB has_sim: which libtsidb build the blob is for
         # ---- TSID side
         "pin_parent": ts["parent"], "pin_place": ts["place"], "pin_inertia": ts["inertia"],
         "pin_frame_parent": ts["frame_parent"], "pin_frame_place": ts["frame_place"],
@@ -481,11 +483,16 @@ def compile_model(ref_root: Path, out: Path):
     return ts, sim, c0, sections
 
 
-def emit_topology_header(mj_parent, path: Path):
-    """Compile-time copy of the sim tree's dof ancestry for the register Cholesky (tree-sparse
-    elimination without run-time branches).  tsidb_create refuses a blob whose tree differs."""
+def emit_topology_header(mj_parent, path: Path, nj=None, na=None, has_sim=True):
+    """Compile-time facts of ONE robot for libtsidb: the dimensions (TSID joints incl. the free-flyer, nq, nv,
+    actuated joints, sim bodies) and the sim tree's dof ancestry for the register Cholesky (tree-sparse elimination
+    without run-time branches).  One library is built per robot (`-DTSIDB_TOPOLOGY_HEADER=...`); tsidb_create refuses
+    a blob whose dimensions or tree differ.  has_sim=False: a TSID-only robot (no MJCF compiled): the sim tree is a
+    placeholder and the library is built without the sim stage."""
     nb = len(mj_parent)
     nv = 6 + nb - 1
+    nj = nb if nj is None else nj
+    na = nv - 6 if na is None else na
     anc_body = []
     for b in range(nb):
         a, m = b, 0
@@ -503,9 +510,12 @@ def emit_topology_header(mj_parent, path: Path):
                 if a != k - 5 and (anc_body[k - 5] >> a) & 1:
                     m |= 0x3F if a == 0 else 1 << (5 + a)
             dofanc.append(m)
-    txt = ("// GENERATED by tsid_control_amd/model_compiler.py from the sim tree of the compiled model blob.\n"
-           "// MJ_DOFANC[k]: bitmask of the dofs that are strict ancestors of dof k (lower indices).\n"
+    txt = ("// GENERATED by tsid_control_amd/model_compiler.py from the compiled model blob.\n"
+           "// Dimensions of the robot this library is built for, and MJ_DOFANC[k]: bitmask of the sim dofs that are\n"
+           "// strict ancestors of dof k (lower indices).\n"
            "#pragma once\nnamespace tsidb {\n"
+           f"constexpr int TOPO_NJ = {nj}, TOPO_NQ = {nj + 6}, TOPO_NV = {nj + 5}, TOPO_NA = {na};\n"
+           f"constexpr int TOPO_HAS_SIM = {1 if has_sim else 0};\n"
            f"constexpr int TOPO_NB = {nb};\n"
            "constexpr int TOPO_PARENT[] = {" + ", ".join(str(int(x)) for x in mj_parent) + "};\n"
            "constexpr unsigned MJ_DOFANC[] = {" + ", ".join(hex(x) + "u" for x in dofanc) + "};\n"
@@ -513,11 +523,34 @@ def emit_topology_header(mj_parent, path: Path):
     path.write_text(txt)
 
 
+def compile_tsid_only(urdf: Path, srdf: Path, frame_names, out: Path):
+    """A robot with only its TSID side compiled (URDF + SRDF): the blob carries the pin_* sections and model_dims;
+    the library built for it has no sim stage.  Used for the v0 robot (robot/v0/robot.urdf, robot.srdf,
+    legacy/op3_conf.py:56-62), whose MJCF uses features outside the built sim subset."""
+    ts = build_tsid_model(urdf, srdf, frame_names)
+    nj = len(ts["names"])
+    sections = {
+        "model_dims": np.array([nj, nj + 6, nj + 5, nj - 1, nj, 0], np.int32),  # NJ NQ NV NA NB has_sim
+        "pin_parent": ts["parent"], "pin_place": ts["place"], "pin_inertia": ts["inertia"],
+        "pin_frame_parent": ts["frame_parent"], "pin_frame_place": ts["frame_place"],
+        "pin_effort": ts["effort"], "pin_velocity": ts["velocity"], "pin_q0": ts["q0"],
+    }
+    write_blob(out, sections)
+    return ts, sections
+
+
 if __name__ == "__main__":
     ref = Path(sys.argv[1] if len(sys.argv) > 1 else "/root/reference")
     out = Path(sys.argv[2] if len(sys.argv) > 2 else Path(__file__).parent / "assets" / "op3_v1.tsidb")
     ts, sim, c0, sec = compile_model(ref, out)
     emit_topology_header(sec["mj_parent"], Path(__file__).parent / "csrc" / "tsidb_topology.hpp")
+    # the v0 robot: TSID side only (its MJCF needs sim features that are not built)
+    v0 = ref / "robot" / "v0"
+    ts0, sec0 = compile_tsid_only(v0 / "robot.urdf", v0 / "robot.srdf",
+                                  ["leg_left_sole_joint_fixed", "leg_right_sole_joint_fixed"],
+                                  out.parent / "op3_v0.tsidb")
+    emit_topology_header(sec0["pin_parent"], Path(__file__).parent / "csrc" / "tsidb_topology_v0.hpp", has_sim=False)
+    print("v0 joints:", ts0["names"], "mass", ts0["inertia"][:, 0].sum())
     print("joints:", ts["names"])
     print("total mass (TSID):", ts["inertia"][:, 0].sum(), " (sim):", sum(b["inertia"].mass for b in sim["bodies"]))
     print("hull verts:", len(sim["hull_v"]), "edges:", len(sim["edges"]), "blob bytes:", out.stat().st_size)

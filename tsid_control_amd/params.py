@@ -70,11 +70,14 @@ def pack_params(conf, effort_limit, velocity_limit):
     cp[0, :] = [-conf.lxn, -conf.lxn, conf.lxp, conf.lxp]
     cp[1, :] = [-conf.lyn, conf.lyp, -conf.lyn, conf.lyp]
     p[P_CPOINTS:P_CPOINTS + 12] = cp.T.reshape(-1)
-    kp_post = conf.kp_posture * np.asarray(conf.gain_vector, dtype=np.float64)
-    p[P_KP_POSTURE:P_KP_POSTURE + 20] = kp_post
-    p[P_KD_POSTURE:P_KD_POSTURE + 20] = 2.0 * np.sqrt(kp_post)
-    p[P_TAU_MAX:P_TAU_MAX + 20] = conf.tau_max_scaling * np.asarray(effort_limit)
-    p[P_V_MAX:P_V_MAX + 20] = conf.v_max_scaling * np.asarray(velocity_limit)
+    na = len(effort_limit)                      # actuated joints of the blob's robot (20 for v1, 18 for v0; at most 20)
+    if na > 20 or len(conf.gain_vector) < na:
+        raise ValueError(f"the parameter vector holds 20 joint entries and conf.gain_vector must cover the robot's {na} joints")
+    kp_post = conf.kp_posture * np.asarray(conf.gain_vector, dtype=np.float64)[:na]
+    p[P_KP_POSTURE:P_KP_POSTURE + na] = kp_post
+    p[P_KD_POSTURE:P_KD_POSTURE + na] = 2.0 * np.sqrt(kp_post)
+    p[P_TAU_MAX:P_TAU_MAX + na] = conf.tau_max_scaling * np.asarray(effort_limit)
+    p[P_V_MAX:P_V_MAX + na] = conf.v_max_scaling * np.asarray(velocity_limit)
     p[P_MAX_ITER] = getattr(conf, "qp_max_iter", 1000)
     p[P_SIM_ENABLED] = 1.0 if getattr(conf, "sim_enabled", True) else 0.0
     p[P_CLOSED_LOOP] = 1.0 if getattr(conf, "closed_loop", False) else 0.0

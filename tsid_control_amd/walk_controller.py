@@ -51,7 +51,11 @@ class WalkController:
         self.dtype = {"f64": torch.float64, "f32": torch.float32}[dt_name]
         self.model = ModelBlob(getattr(conf, "model_blob", None))
         self.params = pack_params(conf, self.model.effort_limit, self.model.velocity_limit)
-        self._L = L = _lib.load()
+        # one library per robot: pick the build whose dimensions are the blob's (libtsidb.so = v1, libtsidb_v0.so = robot/v0)
+        self._L = L = _lib.load_for(self.model["model_dims"])
+        NJ_, NQ, NV, NA, _nb, self.has_sim = _lib.dims(L)
+        NOBS, NROW = NQ + NV + 12, NQ + NV + 14
+        self.NQ, self.NV, self.NA, self.NOBS, self.NROW = NQ, NV, NA, NOBS, NROW
         self._h = C.c_void_p()
         raw = self.model.raw
         rc = L.tsidb_create(raw, len(raw), self.params.ctypes.data_as(C.c_void_p), P_COUNT, N, self.device.index,
@@ -211,7 +215,7 @@ class WalkController:
         with torch.cuda.device(self.device):
             rc = self._L.tsidb_step(self._h, _ptr(self.q), _ptr(self.v), _ptr(self.qpos), _ptr(self.qvel),
                                     _ptr(self.qacc_warmstart), _ptr(self.tau), _ptr(self.dv), _ptr(self.f),
-                                    _ptr(self.status), _ptr(self.rows), NROW, _ptr(self.frames), _ptr(self.ncon),
+                                    _ptr(self.status), _ptr(self.rows), self.NROW, _ptr(self.frames), _ptr(self.ncon),
                                     _ptr(self.con_pairs), _ptr(self.info), int(n_substeps), self._stream())
         _lib.check(self._L, self._h, rc, "tsidb_step")
         self.t += n_substeps * self.conf.dt
@@ -326,7 +330,7 @@ class WalkController:
         """TSID stage only (main.py:119-129)."""
         with torch.cuda.device(self.device):
             rc = self._L.tsidb_tick(self._h, _ptr(self.q), _ptr(self.v), _ptr(self.tau), _ptr(self.dv), _ptr(self.f),
-                                    _ptr(self.status), _ptr(self.rows), NROW, _ptr(self.frames), _ptr(self.info), self._stream())
+                                    _ptr(self.status), _ptr(self.rows), self.NROW, _ptr(self.frames), _ptr(self.info), self._stream())
         _lib.check(self._L, self._h, rc, "tsidb_tick")
         return self.tau, self.q, self.v, self.status, self.obs
 
@@ -353,6 +357,7 @@ class WalkController:
         v = self.v if v is None else v
         N = self.num_envs
         z = lambda *s: torch.zeros(*s, dtype=self.dtype, device=self.device)
+        NV = self.NV
         out = dict(M=z(N, NV, NV), h=z(N, NV), Jcom=z(N, 3, NV), Jf=z(N, 2, 6, NV), oMf=z(N, 2, 12), com=z(N, 3))
         with torch.cuda.device(self.device):
             rc = self._L.tsidb_rbd_terms(self._h, _ptr(q), _ptr(v), _ptr(out["M"]), _ptr(out["h"]), _ptr(out["Jcom"]),
@@ -412,7 +417,8 @@ class WalkController:
     def get_cop(self, sol=None):
         """WalkController.py:255-289: centre of pressure of the last tick's contact forces, [N,3];
         rows are NaN where the reference would return None (not both feet in contact)."""
-        cop = self.obs[:, 56:59].clone()
+        o = self.NQ + self.NV
+        cop = self.obs[:, o + 3:o + 6].clone()
         both = self.contactLF_active & self.contactRF_active
         cop[~both] = float("nan")
         return cop
@@ -420,7 +426,7 @@ class WalkController:
     def compute_capture_point(self, com=None, dcom=None, w=None):
         """legacy/biped.py:224-227, batched: cp = com + dcom / w with cp_z = 0; defaults to the last tick's
         CoM / CoM velocity (obs) and the LIPM frequency of the current CoM height."""
-        com = self.obs[:, 53:56] if com is None else com
+        com = self.obs[:, self.NQ + self.NV:self.NQ + self.NV + 3] if com is None else com
         if dcom is None:
             raise ValueError("dcom (CoM velocity [N,3]) is required: the observation vector carries positions only")
         if w is None:
