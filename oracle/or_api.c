@@ -65,7 +65,7 @@ int or_env_step_batch_walk(const OrModel *m, const double *params, int n, double
                         foot_ref + (size_t)e * 48, contact_ref + (size_t)e * 24, contact_active + (size_t)e * 2,
                         com_ref + (size_t)e * 9, w->td_latch ? ncon + e : NULL,
                         w->td_latch ? con_geom + (size_t)e * OR_MAXCON : NULL, w->td_latch ? w->td_latch + e : NULL,
-                        m->foot_body[0], m->foot_body[1], w->td_frac);
+                        m->foot_geoms[0], m->foot_geoms[1], w->td_frac);
     if (closed) sim_to_tsid(m, qpos + (size_t)e * OR_NQ, qvel + (size_t)e * OR_NV, qe, ve);
     int st = or_tsid_tick_cop(m, params, qe, ve, com_ref + (size_t)e * 9, posture_ref + (size_t)e * OR_NA,
                               foot_ref + (size_t)e * 48, contact_ref + (size_t)e * 24, contact_active + (size_t)e * 2,

@@ -1,8 +1,11 @@
 /* or_collide.c - terrain height and convex-hull <-> convex-hull narrow phase (TEST INFRASTRUCTURE; see oracle.h).
  *
- * What mujoco.mj_step (main.py:195) does for the 170 robot<->robot candidate body pairs that survive the
- * excludes and the parent-child filter of robot/v1/mujoco/robot.xml:18-52: each pair of collision meshes
- * (robot.xml:13-15) is collided as a pair of convex hulls.  mujoco is not vendored: PARITY
+ * What mujoco.mj_step (main.py:195) does for the robot<->robot candidate geom pairs that survive the
+ * excludes and the parent-child / same-body filter (170 for robot/v1/mujoco/robot.xml:18-52, 1044 for
+ * robot/v0/robot.xml whose "visual" meshes collide too: they inherit contype 1 from robot.xml:4): each pair of
+ * collision meshes is collided as a pair of convex hulls.  A geom margin (robot/v0/robot.xml:4) inflates both
+ * hulls by margin / 2 along the support direction (mjc_Convex's support function); the caller then takes
+ * dist = margin - depth and keeps the contact while dist < margin.  mujoco is not vendored: PARITY
  * UNPINNED.  This restates the published algorithm MuJoCo's mjc_Convex has used for mesh pairs - Minkowski
  * Portal Refinement (Snethen 2008, "XenoCollide"; libccd's ccdMPRPenetration): portal discovery from the
  * interior point centre1 - centre2, portal refinement, penetration = distance from the origin to the final
@@ -48,7 +51,7 @@ double or_terrain_height(const double *terr, double X, double Y) {
   return terr[4 + cell];
 }
 
-/* support vertex of body b's hull (placed at R, p) along the world direction d: index (hull-local) and world point */
+/* support vertex of geom b's hull (its body placed at R, p) along the world direction d: index (hull-local) and world point */
 static int hull_support(const OrModel *m, int b, const double *R, const double *p, const double *d, double *w) {
   const double db[3] = {R[0] * d[0] + R[3] * d[1] + R[6] * d[2], R[1] * d[0] + R[4] * d[1] + R[7] * d[2],
                         R[2] * d[0] + R[5] * d[1] + R[8] * d[2]};
@@ -72,13 +75,17 @@ typedef struct {
   const OrModel *m;
   int a, b;
   const double *Ra, *pa, *Rb, *pb;
+  double margin;
 } Pair;
 
+/* dir is a unit vector at every call */
 static void support(const Pair *P, const double *dir, Sup *s) {
   double wa[3], wb[3], nd[3] = {-dir[0], -dir[1], -dir[2]};
   s->ia = hull_support(P->m, P->a, P->Ra, P->pa, dir, wa);
   s->ib = hull_support(P->m, P->b, P->Rb, P->pb, nd, wb);
   sub(wa, wb, s->v);
+  /* each hull grown by margin / 2 along its own support direction: A - B grows by margin along dir */
+  if (P->margin != 0) for (int i = 0; i < 3; i++) s->v[i] += P->margin * dir[i];
 }
 
 static void portal_dir(const Sup *v1, const Sup *v2, const Sup *v3, double *dir) {
@@ -144,7 +151,12 @@ static void world_vertex(const OrModel *m, int b, const double *R, const double 
  * depth * dir separates them) and the contact point pos; 0 if the hulls do not intersect (or only touch). */
 int or_mpr_penetration(const OrModel *m, int a, const double *Ra, const double *pa, int b, const double *Rb,
                        const double *pb, double *depth, double *dir_out, double *pos) {
-  const Pair P = {m, a, b, Ra, pa, Rb, pb};
+  return or_mpr_penetration_margin(m, a, Ra, pa, b, Rb, pb, 0.0, depth, dir_out, pos);
+}
+
+int or_mpr_penetration_margin(const OrModel *m, int a, const double *Ra, const double *pa, int b, const double *Rb,
+                              const double *pb, double margin, double *depth, double *dir_out, double *pos) {
+  const Pair P = {m, a, b, Ra, pa, Rb, pb, margin};
   Sup v0, v1, v2, v3, v4;
   double ca[3], cb[3], dir[3], va[3], vb[3];
   /* interior point: centre of a minus centre of b */
@@ -272,31 +284,37 @@ static int boxes_overlap(const double *Ra, const double *ca, const double *ha, c
   return 1;
 }
 
-/* Robot<->robot contacts for one env: every candidate pair (mj_pairs order) through bounding spheres, boxes, MPR.
- * Rb / pb: world placements of the bodies.  Appends at most OR_MAXHH contacts (and never beyond OR_MAXCON in
- * total); returns the number appended, *overflow set when a penetrating pair had to be dropped. */
-int or_collide_pairs(const OrModel *m, const double Rb[][9], const double pb[][3], int ncon0, int *body1, int *body2,
+/* Robot<->robot contacts for one env: every candidate geom pair (mj_pairs order) through bounding spheres, boxes,
+ * MPR.  Rb / pb: world placements of the bodies.  Appends at most OR_MAXHH contacts (and never beyond OR_MAXCON in
+ * total); returns the number appended, *overflow set when a penetrating pair had to be dropped (also when more than
+ * 64 pairs survive the mid phase: the device works through at most one wavefront's worth of candidates). */
+int or_collide_pairs(const OrModel *m, const double Rb[][9], const double pb[][3], int ncon0, int *geom1, int *geom2,
                      double *dist, double (*pos)[3], double (*nrm)[3], int *overflow) {
-  int n = 0;
+  int n = 0, ncand = 0;
+  const double margin = m->contact[10], hm = 0.5 * margin;
   *overflow = 0;
   for (int k = 0; k < m->npair; k++) {
     const int a = m->pairs[2 * k], b = m->pairs[2 * k + 1];
+    const int Ba = m->geom_body[a], Bb = m->geom_body[b];
     double ca[3], cb[3], d[3], ba[3], bb[3];
     for (int i = 0; i < 3; i++) {
-      ca[i] = Rb[a][3 * i] * m->rbound[a][0] + Rb[a][3 * i + 1] * m->rbound[a][1] + Rb[a][3 * i + 2] * m->rbound[a][2] + pb[a][i];
-      cb[i] = Rb[b][3 * i] * m->rbound[b][0] + Rb[b][3 * i + 1] * m->rbound[b][1] + Rb[b][3 * i + 2] * m->rbound[b][2] + pb[b][i];
-      ba[i] = Rb[a][3 * i] * m->hull_box[a][0] + Rb[a][3 * i + 1] * m->hull_box[a][1] + Rb[a][3 * i + 2] * m->hull_box[a][2] + pb[a][i];
-      bb[i] = Rb[b][3 * i] * m->hull_box[b][0] + Rb[b][3 * i + 1] * m->hull_box[b][1] + Rb[b][3 * i + 2] * m->hull_box[b][2] + pb[b][i];
+      ca[i] = Rb[Ba][3 * i] * m->rbound[a][0] + Rb[Ba][3 * i + 1] * m->rbound[a][1] + Rb[Ba][3 * i + 2] * m->rbound[a][2] + pb[Ba][i];
+      cb[i] = Rb[Bb][3 * i] * m->rbound[b][0] + Rb[Bb][3 * i + 1] * m->rbound[b][1] + Rb[Bb][3 * i + 2] * m->rbound[b][2] + pb[Bb][i];
+      ba[i] = Rb[Ba][3 * i] * m->hull_box[a][0] + Rb[Ba][3 * i + 1] * m->hull_box[a][1] + Rb[Ba][3 * i + 2] * m->hull_box[a][2] + pb[Ba][i];
+      bb[i] = Rb[Bb][3 * i] * m->hull_box[b][0] + Rb[Bb][3 * i + 1] * m->hull_box[b][1] + Rb[Bb][3 * i + 2] * m->hull_box[b][2] + pb[Bb][i];
     }
     sub(ca, cb, d);
-    const double rr = m->rbound[a][3] + m->rbound[b][3];
+    const double rr = m->rbound[a][3] + m->rbound[b][3] + margin;
     if (dot(d, d) > rr * rr) continue;
-    if (!boxes_overlap(Rb[a], ba, m->hull_box[a] + 3, Rb[b], bb, m->hull_box[b] + 3)) continue;
+    const double ha[3] = {m->hull_box[a][3] + hm, m->hull_box[a][4] + hm, m->hull_box[a][5] + hm};
+    const double hb[3] = {m->hull_box[b][3] + hm, m->hull_box[b][4] + hm, m->hull_box[b][5] + hm};
+    if (!boxes_overlap(Rb[Ba], ba, ha, Rb[Bb], bb, hb)) continue;
+    if (++ncand > 64) { *overflow = 1; break; }
     double depth, dir[3], p[3];
-    if (!or_mpr_penetration(m, a, Rb[a], pb[a], b, Rb[b], pb[b], &depth, dir, p)) continue;
+    if (!or_mpr_penetration_margin(m, a, Rb[Ba], pb[Ba], b, Rb[Bb], pb[Bb], margin, &depth, dir, p)) continue;
     if (n >= OR_MAXHH || ncon0 + n >= OR_MAXCON) { *overflow = 1; continue; }
-    body1[n] = a; body2[n] = b;
-    dist[n] = -depth;
+    geom1[n] = a; geom2[n] = b;
+    dist[n] = margin - depth;
     memcpy(pos[n], p, 24);
     memcpy(nrm[n], dir, 24);
     n++;

@@ -62,8 +62,9 @@ OrModel *or_model_load(const void *blob, size_t nbytes) {
   e |= getf(b, "pin_velocity", m->velocity, OR_NA);
   e |= getf(b, "pin_q0", m->q0, OR_NQ);
   {
-    int md[6] = {0};
-    if (geti(b, "model_dims", md, 6) || md[0] != OR_NJ || md[3] != OR_NA || md[5] != OR_HAS_SIM) {
+    int md[9] = {0}; /* NJ NQ NV NA NB has_sim NG condim eulerdamp */
+    if (geti(b, "model_dims", md, 9) || md[0] != OR_NJ || md[3] != OR_NA || md[5] != OR_HAS_SIM ||
+        (OR_HAS_SIM && (md[4] != OR_NB || md[6] != OR_NG || md[7] != OR_CONDIM))) {
       fprintf(stderr, "oracle: the blob is for another robot than this build\n");
       e |= -1;
     }
@@ -87,17 +88,21 @@ OrModel *or_model_load(const void *blob, size_t nbytes) {
   e |= getf(b, "mj_act_kp", m->mj_act_kp, OR_NA);
   e |= getf(b, "mj_act_kv", m->mj_act_kv, OR_NA);
   e |= geti(b, "mj_ctrl_qidx", m->mj_ctrl_qidx, OR_NA);
-  e |= geti(b, "mj_hull_adr", m->hull_adr, OR_NB + 1);
-  e |= getf(b, "mj_rbound", &m->rbound[0][0], OR_NB * 4);
-  e |= getf(b, "mj_hull_center", &m->hull_center[0][0], OR_NB * 3);
-  e |= getf(b, "mj_hull_box", &m->hull_box[0][0], OR_NB * 6);
+  e |= getf(b, "mj_damping", m->mj_damping, OR_NV);
+  e |= getf(b, "mj_act_range", &m->act_range[0][0], OR_NA * 4);
+  e |= geti(b, "mj_geom_body", m->geom_body, OR_NG);
+  e |= geti(b, "mj_hull_adr", m->hull_adr, OR_NG + 1);
+  e |= getf(b, "mj_rbound", &m->rbound[0][0], OR_NG * 4);
+  e |= getf(b, "mj_hull_center", &m->hull_center[0][0], OR_NG * 3);
+  e |= getf(b, "mj_hull_box", &m->hull_box[0][0], OR_NG * 6);
   {
     const Sect *ps = find(b, "mj_pairs");
     if (!ps || ps->dtype != 1 || ps->count > 2 * OR_MAXPAIR) e |= -1;
     else { m->npair = (int)(ps->count / 2); memcpy(m->pairs, b + ps->offset, ps->count * sizeof(int)); }
   }
   e |= getf(b, "mj_opt", m->opt, 7);
-  e |= getf(b, "mj_contact", m->contact, 8);
+  e |= getf(b, "mj_contact", m->contact, 12);
+  if (!e && (int)m->contact[8] != OR_CONDIM) e |= -1;
   const Sect *hv = find(b, "mj_hull_vert"), *ea = find(b, "mj_hull_eadr"), *ed = find(b, "mj_hull_edge");
   if (e || !hv || !ea || !ed) {
     or_model_free(m);
@@ -120,6 +125,11 @@ OrModel *or_model_load(const void *blob, size_t nbytes) {
       for (int f = 0; f < 2; f++)
         for (int i = 0; i < OR_NA; i++)
           if (s2t[i] == m->frame_parent[f] - 1) m->foot_body[f] = 1 + i;
+    for (int f = 0; f < 2; f++) {
+      m->foot_geoms[f] = 0;
+      for (int g = 0; g < OR_NG; g++)
+        if (m->geom_body[g] == m->foot_body[f]) m->foot_geoms[f] |= (uint64_t)1 << g;
+    }
   }
   return m;
 }

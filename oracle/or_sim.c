@@ -4,7 +4,10 @@
  * robot/v1/mujoco/scene.xml + robot.xml compile to: one free joint + 20 z-hinges,
  * armature, frictionloss rows, position actuators (kp, kv from dampratio), floor-plane <-> convex
  * hull contacts, soft constraints (solref/solimp impedance), pyramidal cones (condim 3), Newton
- * solver with warm start, semi-implicit Euler.  mujoco is not vendored; this follows
+ * solver with warm start, semi-implicit Euler - and, for robot/v0/robot.xml (-DOR_ROBOT_V0): several
+ * collision geoms per body, condim 4 (torsional friction: two more pyramid rows per contact), joint damping
+ * as a passive force integrated implicitly (mj_Euler's (M + h B) solve), the geom margin, and the position
+ * actuators' ctrlrange / forcerange clamps.  mujoco is not vendored; this follows
  * the published algorithm (MuJoCo documentation, "Computation" chapter; Todorov 2014) with every
  * option at its default except timestep (main.py:52).
  *
@@ -302,10 +305,21 @@ int or_sim_step_ext(const OrModel *m, double *qpos, double *qvel, const double *
   for (int a = 0; a < OR_NA; a++) {
     int d = m->mj_act_dof[a];
     if (motor_tau) info->qfrc_actuator[d] += motor_tau[m->mj_ctrl_qidx[a] - 7];
-    else info->qfrc_actuator[d] += m->mj_act_kp[a] * (ctrl[a] - qpos[d + 1]) - m->mj_act_kv[a] * qvel[d];
+    else {
+      /* ctrllimited: the control is clamped to ctrlrange; forcelimited: the actuator force to forcerange */
+      const double *rg = m->act_range[a];
+      const double c = fmin(fmax(ctrl[a], rg[0]), rg[1]);
+      const double frc = m->mj_act_kp[a] * (c - qpos[d + 1]) - m->mj_act_kv[a] * qvel[d];
+      info->qfrc_actuator[d] += fmin(fmax(frc, rg[2]), rg[3]);
+    }
   }
+  /* qfrc_smooth = passive (joint damping) + actuator - bias */
   double qfrc_smooth[NV];
-  for (int k = 0; k < NV; k++) qfrc_smooth[k] = info->qfrc_actuator[k] - info->qfrc_bias[k];
+  int any_damping = 0;
+  for (int k = 0; k < NV; k++) {
+    qfrc_smooth[k] = info->qfrc_actuator[k] - info->qfrc_bias[k] - m->mj_damping[k] * qvel[k];
+    if (m->mj_damping[k] > 0) any_damping = 1;
+  }
   double L[NV][NV];
   memcpy(L, M, sizeof L);
   if (chol(L, NV)) return -1;
@@ -319,19 +333,20 @@ int or_sim_step_ext(const OrModel *m, double *qpos, double *qvel, const double *
    * height of the cell under each point */
   double hmax = 0.0;
   if (terr) for (int i = 0; i < 16; i++) hmax = fmax(hmax, terr[4 + i]);
-  const double margin = 0.0;
+  const double margin = m->contact[10]; /* max of the two geoms' margins: the floor inherits the robot's (robot/v0/robot.xml:4,59) */
   int ncon = 0;
-  for (int b = 0; b < NB && ncon < OR_MAXCON; b++) {
+  for (int g = 0; g < OR_NG && ncon < OR_MAXCON; g++) {
+    const int b = m->geom_body[g];
     double cw[3];
-    matvec(Rb[b], m->rbound[b], cw);
+    matvec(Rb[b], m->rbound[g], cw);
     for (int i = 0; i < 3; i++) cw[i] += pb[b][i];
-    if (dot3(nrm, cw) - pd - m->rbound[b][3] - hmax > margin) continue;
+    if (dot3(nrm, cw) - pd - m->rbound[g][3] - hmax > margin) continue;
     /* floor normal in the body frame, plane offset seen from the body origin */
     const double rn[3] = {nrm[0] * Rb[b][0] + nrm[1] * Rb[b][3] + nrm[2] * Rb[b][6],
                           nrm[0] * Rb[b][1] + nrm[1] * Rb[b][4] + nrm[2] * Rb[b][7],
                           nrm[0] * Rb[b][2] + nrm[1] * Rb[b][5] + nrm[2] * Rb[b][8]};
     const double pz = dot3(nrm, pb[b]) - pd;
-    int v0 = m->hull_adr[b], v1 = m->hull_adr[b + 1];
+    int v0 = m->hull_adr[g], v1 = m->hull_adr[g + 1];
     double zmin = INFINITY;
 #define VERT_DIST(i, z)                                                                     \
   do {                                                                                      \
@@ -366,7 +381,8 @@ int or_sim_step_ext(const OrModel *m, double *qpos, double *qvel, const double *
       for (int i = 0; i < 3; i++) w[i] += pb[b][i];
       double dist = dot3(nrm, w) - pd - or_terrain_height(terr, w[0], w[1]);
       if (c > 0 && dist > margin) continue;
-      info->con_geom[ncon] = b;
+      info->con_geom[ncon] = g;
+      info->con_body2[ncon] = b;
       info->con_vert[ncon] = cand[c] - v0;
       info->con_body1[ncon] = -1;
       memcpy(info->con_frame[ncon], nrm, sizeof nrm);
@@ -378,13 +394,14 @@ int or_sim_step_ext(const OrModel *m, double *qpos, double *qvel, const double *
 #undef VERT_DIST
   /* ---------------- collision: robot<->robot convex-hull pairs (robot.xml:13-15,18-52; or_collide.c) */
   if (self_collision) {
-    int b1[OR_MAXHH], b2[OR_MAXHH], over = 0;
+    int g1[OR_MAXHH], g2[OR_MAXHH], over = 0;
     double hd[OR_MAXHH], hp[OR_MAXHH][3], hn[OR_MAXHH][3];
-    const int nh = or_collide_pairs(m, Rb, pb, ncon, b1, b2, hd, hp, hn, &over);
+    const int nh = or_collide_pairs(m, Rb, pb, ncon, g1, g2, hd, hp, hn, &over);
     for (int k = 0; k < nh; k++, ncon++) {
-      info->con_geom[ncon] = b2[k];
-      info->con_vert[ncon] = 0x8000 | b1[k];
-      info->con_body1[ncon] = b1[k];
+      info->con_geom[ncon] = g2[k];
+      info->con_body2[ncon] = m->geom_body[g2[k]];
+      info->con_vert[ncon] = 0x8000 | g1[k];
+      info->con_body1[ncon] = m->geom_body[g1[k]];
       memcpy(info->con_frame[ncon], hn[k], 24);
       info->con_dist[ncon] = hd[k];
       memcpy(info->con_pos[ncon], hp[k], 24);
@@ -400,28 +417,32 @@ int or_sim_step_ext(const OrModel *m, double *qpos, double *qvel, const double *
   const double timeconst = m->contact[1] > 2 * dt ? m->contact[1] : 2 * dt, dampratio = m->contact[2];
   const double dmin = m->contact[3], dmax = m->contact[4], width = m->contact[5], mid = m->contact[6], power = m->contact[7];
   const double kk = 1.0 / (dmax * dmax * timeconst * timeconst * dampratio * dampratio), bb = 2.0 / (dmax * timeconst);
+  /* frictionloss rows use the joint's solreffriction / solimpfriction, which neither MJCF sets: MuJoCo's defaults
+   * (0.02, 1) and the default solimp (the geoms' solref of robot/v0/robot.xml:4 does not apply to them) */
+  const double tc_f = 0.02 > 2 * dt ? 0.02 : 2 * dt, bb_f = 2.0 / (dmax * tc_f);
   for (int k = 0; k < NV; k++) {
     if (m->mj_frictionloss[k] <= 0) continue;
     int r = e.nefc++;
     memset(e.J[r], 0, sizeof e.J[r]);
     e.J[r][k] = 1.0;
     double imp = dmin; /* pos = 0 */
-    e.aref[r] = -bb * qvel[k];
+    e.aref[r] = -bb_f * qvel[k];
     e.R[r] = fmax(MINVAL, (1 - imp) / imp * m->mj_dof_invw0[k]);
     e.D[r] = 1.0 / e.R[r];
     e.floss[r] = m->mj_frictionloss[k] * m->floss_scale;
     e.type[r] = 0;
   }
   for (int c = 0; c < ncon; c++) {
-    int b = info->con_geom[c];
+    int b = info->con_body2[c];
     const int b1 = info->con_body1[c];
     const double *r = info->con_pos[c], *nrm = info->con_frame[c];
     const double mu = b1 >= 0 ? m->contact[0] : mu_floor; /* robot geoms keep the model's friction */
     double t1[3], t2[3];
     make_frame(nrm, t1, t2);
     /* point Jacobian of geom2's body minus that of geom1's body (the floor does not move) */
-    double Jp[3][NV];
+    double Jp[3][NV], Jr[3][NV]; /* Jr: relative angular velocity of the two bodies per unit dof rate */
     memset(Jp, 0, sizeof Jp);
+    memset(Jr, 0, sizeof Jr);
     for (int side = 0; side < 2; side++) {
       const double sg = side == 0 ? 1.0 : -1.0;
       for (int a = side == 0 ? b : b1; a >= 0; a = m->mj_parent[a]) {
@@ -429,16 +450,21 @@ int or_sim_step_ext(const OrModel *m, double *qpos, double *qvel, const double *
         for (int k = k0; k <= k1; k++) {
           double wxr[3];
           cross(S[k] + 3, r, wxr);
-          for (int i = 0; i < 3; i++) Jp[i][k] += sg * (S[k][i] + wxr[i]);
+          for (int i = 0; i < 3; i++) { Jp[i][k] += sg * (S[k][i] + wxr[i]); Jr[i][k] += sg * S[k][3 + i]; }
         }
       }
     }
-    double Jn[NV], Jt[2][NV];
+    /* friction directions of the pyramid: the two tangents (sliding, coefficient mu) and, with condim 4, the
+     * rotation about the normal (torsional, coefficient contact[9]) */
+    double Jn[NV], Jt[OR_CONDIM - 1][NV], muk[OR_CONDIM - 1];
     for (int k = 0; k < NV; k++) {
       Jn[k] = nrm[0] * Jp[0][k] + nrm[1] * Jp[1][k] + nrm[2] * Jp[2][k];
       Jt[0][k] = t1[0] * Jp[0][k] + t1[1] * Jp[1][k] + t1[2] * Jp[2][k];
       Jt[1][k] = t2[0] * Jp[0][k] + t2[1] * Jp[1][k] + t2[2] * Jp[2][k];
+      if (OR_CONDIM > 3) Jt[OR_CONDIM - 2][k] = nrm[0] * Jr[0][k] + nrm[1] * Jr[1][k] + nrm[2] * Jr[2][k];
     }
+    muk[0] = muk[1] = mu;
+    if (OR_CONDIM > 3) muk[OR_CONDIM - 2] = m->contact[9];
     double dist = info->con_dist[c];
     /* impedance from penetration */
     double x = fabs(dist - margin) / width, imp;
@@ -454,12 +480,13 @@ int or_sim_step_ext(const OrModel *m, double *qpos, double *qvel, const double *
     double diagA = tran + mu * mu * tran;
     double R0 = fmax(MINVAL, (1 - imp) / imp * diagA);
     double Rpy = 2 * mu * mu * R0;
-    for (int tdir = 0; tdir < 2; tdir++)
+    /* (every row of the pyramid gets Rpy, derived from the first row's diagonal approximation: mj_makeImpedance) */
+    for (int tdir = 0; tdir < OR_CONDIM - 1; tdir++)
       for (int sg = 0; sg < 2; sg++) {
         int rI = e.nefc++;
         double vel = 0;
         for (int k = 0; k < NV; k++) {
-          e.J[rI][k] = Jn[k] + (sg ? -mu : mu) * Jt[tdir][k];
+          e.J[rI][k] = Jn[k] + (sg ? -muk[tdir] : muk[tdir]) * Jt[tdir][k];
           vel += e.J[rI][k] * qvel[k];
         }
         e.aref[rI] = -bb * vel - kk * imp * (dist - margin);
@@ -570,7 +597,20 @@ int or_sim_step_ext(const OrModel *m, double *qpos, double *qvel, const double *
   memcpy(info->qacc, qacc, sizeof qacc);
   memcpy(qacc_ws, qacc, sizeof qacc);
 
-  /* ---------------- semi-implicit Euler */
+  /* ---------------- semi-implicit Euler; with joint damping mj_Euler integrates it implicitly:
+   * (M + h B) qacc_int = qfrc_smooth + qfrc_constraint = M qacc   (the warm start keeps the plain qacc) */
+  if (any_damping) {
+    double Mq[NV], A[NV][NV];
+    for (int i = 0; i < NV; i++) {
+      double s_ = 0;
+      for (int j = 0; j < NV; j++) s_ += M[i][j] * qacc[j];
+      Mq[i] = s_;
+    }
+    memcpy(A, M, sizeof A);
+    for (int i = 0; i < NV; i++) A[i][i] += dt * m->mj_damping[i];
+    if (chol(A, NV)) return -3;
+    chol_solve(A, NV, Mq, qacc);
+  }
   for (int k = 0; k < NV; k++) qvel[k] += dt * qacc[k];
   for (int i = 0; i < 3; i++) qpos[i] += dt * qvel[i];
   {

@@ -39,18 +39,18 @@ void or_walk_update(int n, const double *coef, const int32_t *side, const int32_
                     double z0, double dz, const double *frames, double *foot_ref, double *contact_ref,
                     uint8_t *contact_active, double *com_ref) {
   or_walk_update_fb(n, coef, side, nsteps, rest, com, K, t, t_off, T, t_start, omega, z0, dz, frames, foot_ref, contact_ref,
-                    contact_active, com_ref, NULL, NULL, NULL, -1, -1, 0.0);
+                    contact_active, com_ref, NULL, NULL, NULL, 0, 0, 0.0);
 }
 
 /* the same with contact-timing feedback (closed loop): latch [n] (initialised to -1, NULL = off) - when the last
- * sim step's contact list (ncon [n], con_geom [n, OR_MAXCON] = body << 16 | vertex) shows the swing foot's body
- * (fbody[side]) on the floor after td_frac of its swing, the touch-down is taken at once: the foot counts as a
- * stance foot for the rest of that step */
+ * sim step's contact list (ncon [n], con_geom [n, OR_MAXCON] = geom << 16 | vertex) shows one of the swing foot's
+ * geoms (bit set of fgeoms[side]) on the floor after td_frac of its swing, the touch-down is taken at once: the foot
+ * counts as a stance foot for the rest of that step */
 void or_walk_update_fb(int n, const double *coef, const int32_t *side, const int32_t *nsteps, const double *rest,
                        const double *com, int K, double t, const double *t_off, double T, double t_start, double omega,
                        double z0, double dz, const double *frames, double *foot_ref, double *contact_ref,
                        uint8_t *contact_active, double *com_ref, const int32_t *ncon, const int32_t *con_geom,
-                       int32_t *latch, int fbody0, int fbody1, double td_frac) {
+                       int32_t *latch, uint64_t fgeoms0, uint64_t fgeoms1, double td_frac) {
   for (int e = 0; e < n; e++) {
     double te = t - (t_off ? t_off[e] : 0.0);
     if (te < 0) te = 0;
@@ -72,10 +72,10 @@ void or_walk_update_fb(int n, const double *coef, const int32_t *side, const int
     if (latch) {
       early = walking && latch[e] == k;
       if (walking && !early && s > td_frac * T) {
-        const int fb = sw_side == 0 ? fbody0 : fbody1;
+        const uint64_t fg = sw_side == 0 ? fgeoms0 : fgeoms1;
         for (int c = 0; c < ncon[e]; c++) {
           const int cp = con_geom[(size_t)e * OR_MAXCON + c];
-          if ((cp >> 16) == fb && !(cp & 0x8000)) early = 1;
+          if (((fg >> (cp >> 16)) & 1u) && !(cp & 0x8000)) early = 1;
         }
       }
       if (early) latch[e] = k;

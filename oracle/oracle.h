@@ -18,16 +18,21 @@
 extern "C" {
 #endif
 
-/* One library per robot, like libtsidb: liboracle.so = the v1 robot (ctrl/conf.py:9-15), liboracle_v0.so (-DOR_ROBOT_V0) =
- * robot/v0, TSID side only (its MJCF needs sim features that are not built). */
+/* One library per robot, like libtsidb: liboracle.so = the v1 robot (ctrl/conf.py:9-15, robot/v1/mujoco/robot.xml),
+ * liboracle_v0.so (-DOR_ROBOT_V0) = robot/v0 (robot.urdf + robot.xml: several collision meshes per body, condim 4,
+ * joint damping, geom margin, actuator ranges).  OR_NG = collision geoms, OR_CONDIM = contact dimension (3: sliding
+ * friction; 4: + torsional friction about the normal). */
 #ifdef OR_ROBOT_V0
-enum { OR_NJ = 19, OR_NQ = 25, OR_NV = 24, OR_NA = 18, OR_NB = 19, OR_NF = 2, OR_HAS_SIM = 0 };
+enum { OR_NJ = 19, OR_NQ = 25, OR_NV = 24, OR_NA = 18, OR_NB = 19, OR_NF = 2, OR_HAS_SIM = 1, OR_NG = 52, OR_CONDIM = 4,
+       OR_MAXPAIR = 1100 };
 #else
-enum { OR_NJ = 21, OR_NQ = 27, OR_NV = 26, OR_NA = 20, OR_NB = 21, OR_NF = 2, OR_HAS_SIM = 1 };
+enum { OR_NJ = 21, OR_NQ = 27, OR_NV = 26, OR_NA = 20, OR_NB = 21, OR_NF = 2, OR_HAS_SIM = 1, OR_NG = 21, OR_CONDIM = 3,
+       OR_MAXPAIR = 256 };
 #endif
 enum { OR_NVAR = OR_NV + 24, OR_NEQ = 18, OR_NIN = 68 + 2 * OR_NA + 2 * OR_NV };
-enum { OR_MAXCON = 32, OR_MAXHH = 12 /* robot<->robot contacts per env */, OR_MAXEFC = OR_NA + 4 * OR_MAXCON,
-       OR_NOBS = OR_NQ + OR_NV + 12, OR_MAXPAIR = 256 };
+enum { OR_NROWC = 2 * (OR_CONDIM - 1) /* pyramid rows per contact */ };
+enum { OR_MAXCON = 32, OR_MAXHH = 12 /* robot<->robot contacts per env */, OR_MAXEFC = OR_NA + OR_NROWC * OR_MAXCON,
+       OR_NOBS = OR_NQ + OR_NV + 12 };
 int or_dims(int *out6); /* NJ, NQ, NV, NA, sim bodies, has_sim of this build */
 
 /* parameter vector indices (RobotConfig values; ctrl/conf.py:21-72) */
@@ -57,19 +62,24 @@ typedef struct {
   int mj_act_dof[OR_NA];
   double mj_act_kp[OR_NA], mj_act_kv[OR_NA];
   int mj_ctrl_qidx[OR_NA];
-  int hull_adr[OR_NB + 1];
+  double mj_damping[OR_NV];    /* joint damping (robot/v0/robot.xml:3; 0 for the v1 robot) */
+  double act_range[OR_NA][4];  /* ctrl lo, hi, force lo, hi (robot/v0/robot.xml:5; +-1e300 = unlimited) */
+  /* collision geoms: convex hulls of the collision meshes, each carried by a body, vertices in that body's frame */
+  int geom_body[OR_NG];
+  int hull_adr[OR_NG + 1];
   int nhullvert, nhulledge;
   const double *hull_vert; /* [nhullvert][3], body frame */
   const int *hull_eadr;    /* [nhullvert+1] */
-  const int *hull_edge;    /* neighbour ids local to the body's hull */
-  double rbound[OR_NB][4];
-  double hull_center[OR_NB][3]; /* centre of mass of the solid hull, body frame */
-  double hull_box[OR_NB][6];    /* body-frame bounding box: centre, half extents */
-  int npair, pairs[2 * OR_MAXPAIR]; /* robot<->robot candidate body pairs (excludes + parent-child filtered) */
-  double opt[7];     /* dt gz tol iters ls_iters ls_tol impratio */
-  double contact[8]; /* mu solref[2] solimp[5] */
+  const int *hull_edge;    /* neighbour ids local to the geom's hull */
+  double rbound[OR_NG][4];
+  double hull_center[OR_NG][3]; /* centre of mass of the solid hull, body frame */
+  double hull_box[OR_NG][6];    /* body-frame bounding box: centre, half extents */
+  int npair, pairs[2 * OR_MAXPAIR]; /* robot<->robot candidate geom pairs (excludes + parent-child + same-body filtered) */
+  double opt[7];      /* dt gz tol iters ls_iters ls_tol impratio */
+  double contact[12]; /* mu solref[2] solimp[5] condim mu_torsion margin spare */
   double meaninertia;
   int foot_body[2];   /* sim bodies carrying the left / right sole frame */
+  uint64_t foot_geoms[2]; /* bit g set: geom g is on that body */
   double floss_scale; /* closed-loop knob params[P_SIM_FLOSS_SCALE] (1 = robot.xml:8), set by the batch entry points */
   void *owned;
 } OrModel;
@@ -134,14 +144,15 @@ int or_tsid_tick_cop(const OrModel *m, const double *params, double *q, double *
 /* MuJoCo-subset step for one env: main.py:195 */
 typedef struct {
   int ncon, nefc, solver_iter;
-  int con_geom[OR_MAXCON]; /* body of geom2 (the mesh); geom1 is the floor plane unless con_body1 >= 0 */
-  int con_vert[OR_MAXCON]; /* floor contacts: hull vertex; robot<->robot contacts: 0x8000 | body of geom1 */
+  int con_geom[OR_MAXCON]; /* geom2 (a mesh); geom1 is the floor plane unless con_body1 >= 0 */
+  int con_vert[OR_MAXCON]; /* floor contacts: hull vertex; robot<->robot contacts: 0x8000 | geom1 */
   double con_dist[OR_MAXCON], con_pos[OR_MAXCON][3];
   double efc_force[OR_MAXEFC];
   double qacc[OR_NV], qacc_smooth[OR_NV], qfrc_bias[OR_NV], qfrc_actuator[OR_NV], M[OR_NV][OR_NV];
-  int con_body1[OR_MAXCON];      /* -1 = floor */
+  int con_body1[OR_MAXCON];      /* body of geom1; -1 = floor */
   double con_frame[OR_MAXCON][3]; /* contact normal (geom1 -> geom2), world */
   int flags;                      /* bit 3 (8): a penetrating robot<->robot pair was dropped (contact caps) */
+  int con_body2[OR_MAXCON];      /* body of geom2 */
 } OrSimInfo;
 int or_sim_step(const OrModel *m, double *qpos, double *qvel, const double *ctrl, double *qacc_ws,
                 OrSimInfo *info);
@@ -155,9 +166,12 @@ int or_sim_step_full(const OrModel *m, double *qpos, double *qvel, const double 
 int or_sim_step_ext(const OrModel *m, double *qpos, double *qvel, const double *ctrl, const double *motor_tau,
                     double *qacc_ws, const double *envp, const double *terr, int self_collision, OrSimInfo *info);
 double or_terrain_height(const double *terr, double X, double Y);
+/* a, b: geoms, each placed by the given rotation / position of the body that carries it */
 int or_mpr_penetration(const OrModel *m, int a, const double *Ra, const double *pa, int b, const double *Rb,
                        const double *pb, double *depth, double *dir_out, double *pos);
-int or_collide_pairs(const OrModel *m, const double Rb[][9], const double pb[][3], int ncon0, int *body1, int *body2,
+int or_mpr_penetration_margin(const OrModel *m, int a, const double *Ra, const double *pa, int b, const double *Rb,
+                              const double *pb, double margin, double *depth, double *dir_out, double *pos);
+int or_collide_pairs(const OrModel *m, const double Rb[][9], const double pb[][3], int ncon0, int *geom1, int *geom2,
                      double *dist, double (*pos)[3], double (*nrm)[3], int *overflow);
 
 /* whole env step (tick + base teleport + ctrl map + sim step): main.py:119-129,192-195 */
@@ -184,7 +198,8 @@ void or_walk_update_fb(int n, const double *coef, const int32_t *side, const int
                        const double *com, int K, double t, const double *t_off, double T, double t_start, double omega,
                        double z0, double dz, const double *frames, double *foot_ref, double *contact_ref,
                        uint8_t *contact_active, double *com_ref, const int32_t *ncon, const int32_t *con_geom,
-                       int32_t *latch, int fbody0, int fbody1, double td_frac);
+                       int32_t *latch, uint64_t fgeoms0, uint64_t fgeoms1 /* geoms of the left / right foot body */,
+                       double td_frac);
 
 /* walking tables for or_env_step_batch_walk (env-major, layouts as or_walk_update) */
 typedef struct {

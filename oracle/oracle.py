@@ -13,9 +13,9 @@ HERE = Path(__file__).parent
 NQ, NV, NA, NVAR, NEQ, NIN, MAXCON, MAXEFC, NOBS = 27, 26, 20, 50, 18, 160, 32, 20 + 4 * 32, 65
 
 
-def _structs(NQ, NV, NA):
+def _structs(NQ, NV, NA, condim=3):
     """ctypes mirrors of oracle.h's structs for a robot's dimensions (one liboracle*.so per robot)"""
-    NVAR, NEQ, NIN, MAXEFC = NV + 24, 18, 68 + 2 * NA + 2 * NV, NA + 4 * MAXCON
+    NVAR, NEQ, NIN, MAXEFC = NV + 24, 18, 68 + 2 * NA + 2 * NV, NA + 2 * (condim - 1) * MAXCON
 
     class OrTerms(C.Structure):
         _fields_ = [("M", C.c_double * (NV * NV)), ("h", C.c_double * NV), ("com", C.c_double * 3),
@@ -40,7 +40,8 @@ def _structs(NQ, NV, NA):
                     ("con_dist", C.c_double * MAXCON), ("con_pos", C.c_double * (3 * MAXCON)),
                     ("efc_force", C.c_double * MAXEFC), ("qacc", C.c_double * NV), ("qacc_smooth", C.c_double * NV),
                     ("qfrc_bias", C.c_double * NV), ("qfrc_actuator", C.c_double * NV), ("M", C.c_double * (NV * NV)),
-                    ("con_body1", C.c_int * MAXCON), ("con_frame", C.c_double * (3 * MAXCON)), ("flags", C.c_int)]
+                    ("con_body1", C.c_int * MAXCON), ("con_frame", C.c_double * (3 * MAXCON)), ("flags", C.c_int),
+                    ("con_body2", C.c_int * MAXCON)]
 
     import types
     return types.SimpleNamespace(OrTerms=OrTerms, OrQP=OrQP, OrQPSol=OrQPSol, OrSimInfo=OrSimInfo, NQ=NQ, NV=NV, NA=NA,
@@ -110,15 +111,17 @@ class Oracle:
             off = 16 + 40 * i
             if blob_bytes[off:off + 24].split(b"\0")[0] == b"model_dims":
                 _, cnt, o = struct.unpack_from("<IIQ", blob_bytes, off + 24)
-                md = struct.unpack_from("<6i", blob_bytes, o)
+                md = struct.unpack_from("<9i", blob_bytes, o)   # NJ NQ NV NA NB has_sim NG condim eulerdamp
         if md is None:
             raise RuntimeError("oracle: the blob has no model_dims section")
-        default = HERE / ("liboracle.so" if md[5] else "liboracle_v0.so")
-        so = Path(lib_path or (os.environ.get("TSIDB_ORACLE_LIB") if md[5] else None) or default)  # env: sanitizer build (v1)
+        v1 = md[0] == 21
+        default = HERE / ("liboracle.so" if v1 else "liboracle_v0.so")
+        so = Path(lib_path or (os.environ.get("TSIDB_ORACLE_LIB") if v1 else None) or default)  # env: sanitizer build (v1)
         if not so.exists():
             build()
         self.lib = L = C.CDLL(str(so))
-        self.S = _structs(md[1], md[2], md[3])
+        self.S = _structs(md[1], md[2], md[3], md[7])
+        self.dims = md
         L.or_model_load.restype = C.c_void_p
         L.or_model_load.argtypes = [C.c_char_p, C.c_size_t]
         for name in ("or_model_free", "or_rbd_terms", "or_rnea", "or_integrate", "or_log6", "or_tsid_assemble", "or_walk_update"):
@@ -219,7 +222,7 @@ class Oracle:
                                       _p(tr) if tr is not None else None, int(bool(self_collision)), C.byref(info))
         nc, ne = info.ncon, info.nefc
         return dict(rc=rc, ncon=nc, nefc=ne, iters=info.solver_iter, con_geom=np.array(info.con_geom)[:nc],
-                    con_body1=np.array(info.con_body1)[:nc], con_frame=np.array(info.con_frame).reshape(MAXCON, 3)[:nc],
+                    con_body1=np.array(info.con_body1)[:nc], con_body2=np.array(info.con_body2)[:nc], con_frame=np.array(info.con_frame).reshape(MAXCON, 3)[:nc],
                     flags=info.flags,
                     con_vert=np.array(info.con_vert)[:nc], con_dist=np.array(info.con_dist)[:nc],
                     con_pos=np.array(info.con_pos).reshape(MAXCON, 3)[:nc], efc_force=np.array(info.efc_force)[:ne],
@@ -227,13 +230,15 @@ class Oracle:
                     qfrc_bias=np.array(info.qfrc_bias), qfrc_actuator=np.array(info.qfrc_actuator),
                     M=np.array(info.M).reshape(NV, NV))
 
-    def mpr(self, a, Ra, pa, b, Rb, pb):
-        """or_mpr_penetration of hull a (placed at Ra, pa) and hull b: None or (depth, dir a->b, pos)."""
+    def mpr(self, a, Ra, pa, b, Rb, pb, margin=0.0):
+        """or_mpr_penetration of geom a's hull (its body placed at Ra, pa) and geom b's: None or (depth, dir a->b, pos).
+        margin: both hulls grown by margin / 2 (the caller's dist = margin - depth)."""
         Ra, pa, Rb, pb = (_f64(np.asarray(x).reshape(-1)) for x in (Ra, pa, Rb, pb))
         depth = C.c_double(0.0)
         d, p = np.zeros(3), np.zeros(3)
-        self.lib.or_mpr_penetration.restype = C.c_int
-        hit = self.lib.or_mpr_penetration(self.m, int(a), _p(Ra), _p(pa), int(b), _p(Rb), _p(pb), C.byref(depth), _p(d), _p(p))
+        self.lib.or_mpr_penetration_margin.restype = C.c_int
+        hit = self.lib.or_mpr_penetration_margin(self.m, int(a), _p(Ra), _p(pa), int(b), _p(Rb), _p(pb), C.c_double(margin),
+                                                 C.byref(depth), _p(d), _p(p))
         return (depth.value, d, p) if hit else None
 
     # ---- batch env step (all arrays float64, env-major, updated in place)

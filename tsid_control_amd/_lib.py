@@ -29,7 +29,7 @@ def dims(L):
 def load_for(model_dims):
     """The library built for a blob's robot (its model_dims section): one libtsidb*.so per robot sits next to this file
     (libtsidb.so = the v1 robot, libtsidb_v0.so = robot/v0).  TSIDB_LIB_PATH (diagnostic builds) is tried first."""
-    want = tuple(int(x) for x in model_dims)
+    want = tuple(int(x) for x in model_dims)[:6]   # (the blob's further entries - geoms, condim, damping - are checked by tsidb_create)
     cands = [LIB_PATH] + sorted(p for p in _HERE.glob("libtsidb*.so") if p != LIB_PATH)
     for p in cands:
         if p.exists():

@@ -106,11 +106,11 @@ class RobotConfig:
 
 
 def op3_v0_conf() -> RobotConfig:
-    """The v0 robot (robot/v0/robot.urdf + robot.srdf: 18 actuated joints, no ankle roll) with the values of its own
-    configuration, legacy/op3_conf.py:11-62 - SURVEY.md 8f-4.  Only its TSID side is compiled (assets/op3_v0.tsidb,
-    libtsidb_v0.so): its MJCF (robot/v0/robot.xml:2-9) needs sim features outside the built subset, so sim_enabled is
-    off.  The stack is this package's (ctrl/WalkController.py's): the joint-bound rows stay in even though
-    legacy/op3_conf.py:21 switches them off (w_joint_bounds = 0; at +-10 x the velocity limit they never activate)."""
+    """The v0 robot (robot/v0/robot.urdf + robot.srdf: 18 actuated joints, no ankle roll; sim model robot/v0/robot.xml)
+    with the values of its own configuration, legacy/op3_conf.py:11-62 - SURVEY.md 8f-4.  Its own blob
+    (assets/op3_v0.tsidb) and its own build of the library (libtsidb_v0.so).  The stack is this package's
+    (ctrl/WalkController.py's): the joint-bound rows stay in even though legacy/op3_conf.py:21 switches them off
+    (w_joint_bounds = 0; at +-10 x the velocity limit they never activate)."""
     from pathlib import Path
     c = RobotConfig()
     c.model_blob = str(Path(__file__).parent / "assets" / "op3_v0.tsidb")
@@ -128,5 +128,4 @@ def op3_v0_conf() -> RobotConfig:
     c.masks_posture = np.ones(18)
     c.gain_vector = np.array([100.0, 100.0, 10.0, 5.0, 5.0, 1.0, 1.0, 10.0, 10.0, 10.0,
                               10.0, 5.0, 5.0, 1.0, 1.0, 10.0, 10.0, 10.0])                                         # op3_conf.py:42-48
-    c.sim_enabled = False
     return c

@@ -178,7 +178,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void k_walk(int n, const T *coef, const int *side, const int *nsteps, const T *rest, const T *com,
                                               int K, T t_now, const T *t_off, T Tstep, T t_start, T omega, T z0, T dz, const T *frames, T *foot_ref,
                                               T *contact_ref, uint8_t *cact, T *com_ref, const int *ncon, const int *con, int *latch,
-                                              int fbody0, int fbody1, T td_frac, const T *t_dev) {
+                                              unsigned long long fgeoms0, unsigned long long fgeoms1, T td_frac, const T *t_dev) {
   // 16 lanes per env: every lane evaluates the (cheap) polynomials, each writes its share of the rows, so
   // the table reads hit one line per env and the reference rows are written as contiguous runs
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -205,10 +205,11 @@ __global__ __launch_bounds__(256) void k_walk(int n, const T *coef, const int *s
     const int lk = latch[e];
     early = walking && lk == k;
     if (walking && !early && s > td_frac * Tstep) {
-      const int fb = sd == 0 ? fbody0 : fbody1, nc = ncon[e];
+      const unsigned long long fg = sd == 0 ? fgeoms0 : fgeoms1; // the collision geoms of the swing foot's body
+      const int nc = ncon[e];
       for (int c = 0; c < nc; c++) {
         const int cp = con[E * MAXCON + c];
-        if ((cp >> 16) == fb && !(cp & 0x8000)) early = true;
+        if (((fg >> (cp >> 16)) & 1ull) && !(cp & 0x8000)) early = true;
       }
     }
   }
@@ -387,6 +388,7 @@ struct tsidb_ctx {
   const uint8_t *contact_active = nullptr;
   const void *env_params = nullptr, *terrain = nullptr, *cop_ref = nullptr;
   int foot_body[2] = {-1, -1}; // sim bodies that carry the left / right sole frame
+  unsigned long long foot_geoms[2] = {0, 0}; // bit g: collision geom g is on that body
   std::string err;
 };
 
@@ -517,13 +519,26 @@ static void build_model(tsidb_ctx *h, DevModel<T> &m) {
   for (int a2 = 0; a2 < NA; a2++) m.tsid2sim[m.mj_ctrl_qidx[a2] - 7] = a2;
   const double *kp = b.f64("mj_act_kp", NA), *kv = b.f64("mj_act_kv", NA);
   for (int i = 0; i < NA; i++) { m.mj_act_kp[i] = (T)kp[i]; m.mj_act_kv[i] = (T)kv[i]; }
-  memcpy(m.hull_adr, b.i32("mj_hull_adr", NB + 1), sizeof m.hull_adr);
-  const double *rb = b.f64("mj_rbound", NB * 4), *op = b.f64("mj_opt", 7), *ct = b.f64("mj_contact", 8);
-  for (int i = 0; i < NB * 4; i++) m.rbound[i / 4][i % 4] = (T)rb[i];
+  memcpy(m.hull_adr, b.i32("mj_hull_adr", NG + 1), sizeof m.hull_adr);
+  memcpy(m.geom_body, b.i32("mj_geom_body", NG), sizeof m.geom_body);
+  for (int g = 0; g < NG; g++)
+    if (m.geom_body[g] < 0 || m.geom_body[g] >= NB || (g > 0 && m.geom_body[g] < m.geom_body[g - 1]))
+      throw std::string("model blob: geoms must be listed in body order");
+  const double *rb = b.f64("mj_rbound", NG * 4), *op = b.f64("mj_opt", 7), *ct = b.f64("mj_contact", 12);
+  for (int i = 0; i < NG * 4; i++) m.rbound[i / 4][i % 4] = (T)rb[i];
+  if ((int)ct[8] != CONDIM) throw std::string("model blob: contact dimension differs from this library's");
+  const double *dmp = b.f64("mj_damping", NV), *ar = b.f64("mj_act_range", NA * 4);
+  bool anyd = false;
+  for (int i = 0; i < NV; i++) { m.mj_damping[i] = (T)dmp[i]; anyd |= dmp[i] != 0.0; }
+  if (anyd != EULERDAMP) throw std::string("model blob: joint damping differs from what this library was built for");
+  for (int i = 0; i < NA * 4; i++) {
+    const double lim = sizeof(T) == 8 ? 1e300 : 1e30;
+    m.act_range[i / 4][i % 4] = (T)(ar[i] > lim ? lim : (ar[i] < -lim ? -lim : ar[i]));
+  }
   for (int i = 0; i < 7; i++) m.opt[i] = (T)op[i];
   m.opt[0] = (T)P[P_DT];                         // main.py:52 mj_model.opt.timestep = conf.dt
   m.opt[6] = sizeof(T) == 8 ? (T)1e-9 : (T)2e-6; // support-vertex tie tolerance
-  for (int i = 0; i < 8; i++) m.contact[i] = (T)ct[i];
+  for (int i = 0; i < 12; i++) m.contact[i] = (T)ct[i];
   const uint32_t nvert = h->blob.count("mj_hull_vert") / 3;
   m.hull_x = (const T *)h->d_hull;
   m.hull_y = m.hull_x + nvert;
@@ -535,14 +550,14 @@ static void build_model(tsidb_ctx *h, DevModel<T> &m) {
     m.npair = (int)(np2 / 2);
     for (int k = 0; k < m.npair; k++) {
       m.pair_a[k] = pp[2 * k]; m.pair_b[k] = pp[2 * k + 1];
-      if (pp[2 * k] < 0 || pp[2 * k] >= NB || pp[2 * k + 1] < 0 || pp[2 * k + 1] >= NB) throw std::string("model blob: bad body pair");
+      if (pp[2 * k] < 0 || pp[2 * k] >= NG || pp[2 * k + 1] < 0 || pp[2 * k + 1] >= NG) throw std::string("model blob: bad geom pair");
     }
-    const double *hc = b.f64("mj_hull_center", NB * 3), *hb = b.f64("mj_hull_box", NB * 6);
-    for (int i = 0; i < NB * 3; i++) m.hcen[i / 3][i % 3] = (T)hc[i];
-    for (int i = 0; i < NB * 6; i++) m.hbox[i / 6][i % 6] = (T)hb[i];
-    if (sizeof(T) == 4) for (int j = 0; j < NB; j++) for (int i = 3; i < 6; i++) m.hbox[j][i] = m.hbox[j][i] * (T)1.00001 + (T)1e-7;
+    const double *hc = b.f64("mj_hull_center", NG * 3), *hb = b.f64("mj_hull_box", NG * 6);
+    for (int i = 0; i < NG * 3; i++) m.hcen[i / 3][i % 3] = (T)hc[i];
+    for (int i = 0; i < NG * 6; i++) m.hbox[i / 6][i % 6] = (T)hb[i];
+    if (sizeof(T) == 4) for (int j = 0; j < NG; j++) for (int i = 3; i < 6; i++) m.hbox[j][i] = m.hbox[j][i] * (T)1.00001 + (T)1e-7;
   }
-  memcpy(m.chunk_adr, b.i32("mj_chunk_adr", NB + 1), sizeof m.chunk_adr);
+  memcpy(m.chunk_adr, b.i32("mj_chunk_adr", NG + 1), sizeof m.chunk_adr);
   m.chunk_box = (const T *)h->d_box;
   m.hull_eadr = h->d_eadr;
   m.hull_edge = h->d_edge;
@@ -644,9 +659,9 @@ int tsidb_create(const void *model_blob, size_t nbytes, const double *params, in
     h->blob.raw.assign((const uint8_t *)model_blob, (const uint8_t *)model_blob + nbytes);
     h->blob.validate();
     { // the blob must be for the robot this library was built for
-      const int want[6] = {NJ, NQ, NV, NA, NB, TOPO_HAS_SIM};
-      const int *got = h->blob.i32("model_dims", 6);
-      for (int i = 0; i < 6; i++)
+      const int want[9] = {NJ, NQ, NV, NA, NB, TOPO_HAS_SIM, NG, CONDIM, TOPO_EULERDAMP};
+      const int *got = h->blob.i32("model_dims", 9);
+      for (int i = 0; i < 9; i++)
         if (got[i] != want[i])
           throw std::string("model blob is for another robot than this library (dimensions differ: build the library with "
                             "the blob's topology header, -DTSIDB_TOPOLOGY_HEADER)");
@@ -664,6 +679,11 @@ int tsidb_create(const void *model_blob, size_t nbytes, const double *params, in
         for (int i = 0; i < NA; i++)
           if (s2t[i] == fp[f] - 1) h->foot_body[f] = 1 + i;
       if (h->foot_body[0] < 0 || h->foot_body[1] < 0) throw std::string("model blob: sole frames are not on sim bodies");
+      static_assert(NG <= 64, "foot geoms are kept as a 64-bit mask");
+      const int *gb = h->blob.i32("mj_geom_body", NG);
+      for (int f = 0; f < 2; f++)
+        for (int g = 0; g < NG; g++)
+          if (gb[g] == h->foot_body[f]) h->foot_geoms[f] |= 1ull << g;
     }
   } catch (const std::string &s) {
     h->err = s;
@@ -791,13 +811,13 @@ int tsidb_walk_update(tsidb_handle h, const void *coef, const int32_t *side, con
     hipLaunchKernelGGL(k_walk<double>, dim3(grid), dim3(256), 0, s, h->num_envs, (const double *)coef, side, nsteps,
                        (const double *)rest, (const double *)com, K, t, (const double *)t_offset, step_duration, t_start, omega, com_z0, com_drop,
                        (const double *)frames, (double *)h->foot_ref, (double *)h->contact_ref, (uint8_t *)h->contact_active,
-                       (double *)h->com_ref, ncon, con_pairs, td_latch, h->foot_body[0], h->foot_body[1], td_fraction,
+                       (double *)h->com_ref, ncon, con_pairs, td_latch, h->foot_geoms[0], h->foot_geoms[1], td_fraction,
                        (const double *)t_device);
   else
     hipLaunchKernelGGL(k_walk<float>, dim3(grid), dim3(256), 0, s, h->num_envs, (const float *)coef, side, nsteps,
                        (const float *)rest, (const float *)com, K, (float)t, (const float *)t_offset, (float)step_duration, (float)t_start, (float)omega,
                        (float)com_z0, (float)com_drop, (const float *)frames, (float *)h->foot_ref, (float *)h->contact_ref,
-                       (uint8_t *)h->contact_active, (float *)h->com_ref, ncon, con_pairs, td_latch, h->foot_body[0], h->foot_body[1],
+                       (uint8_t *)h->contact_active, (float *)h->com_ref, ncon, con_pairs, td_latch, h->foot_geoms[0], h->foot_geoms[1],
                        (float)td_fraction, (const float *)t_device);
   HIP_OK(hipGetLastError());
   GUARD_END
@@ -829,7 +849,7 @@ int tsidb_debug_stamps(unsigned long long *out, int n) {
 /* dimensions of the robot this library was built for: NJ, NQ, NV, NA, NB (sim bodies), 1 if the sim stage is built */
 int tsidb_dims(int *out6) {
   if (!out6) return -1;
-  const int d[6] = {NJ, NQ, NV, NA, NB, TOPO_HAS_SIM};
+  const int d[6] = {NJ, NQ, NV, NA, NB, TOPO_HAS_SIM}; // (the blob's model_dims also carries NG, condim, damping)
   for (int i = 0; i < 6; i++) out6[i] = d[i];
   return 0;
 }

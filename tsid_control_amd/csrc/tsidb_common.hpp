@@ -41,7 +41,12 @@ static_assert(NJ == NV - 5 && NQ == NV + 1 && NA == NV - 6, "one free-flyer + hi
 static_assert(NJ <= 32 && NB <= 32 && NVAR <= 64 && NA <= 20 && 32 + NA <= 64, "lane / bitmask / parameter-vector limits");
 constexpr int MAXCON = 32;
 constexpr int MAXHH = 12;    // robot<->robot contacts per env (the last slots of the contact list)
-constexpr int MAXPAIR = 192; // candidate body pairs (three rounds of one lane per pair)
+constexpr int MAXPAIR = TOPO_MAXPAIR; // candidate geom pairs (rounds of one lane per pair); 192 for the v1 robot
+constexpr int NG = TOPO_NG;           // collision geoms = convex hulls (one per body in the v1 robot)
+constexpr int CONDIM = TOPO_CONDIM;   // contact dimension: 3 (robot/v1) or 4 (+ torsional friction, robot/v0/robot.xml:4)
+constexpr int NROWC = 2 * (CONDIM - 1); // pyramidal rows per contact
+constexpr bool EULERDAMP = TOPO_EULERDAMP != 0; // joint damping, integrated implicitly as MuJoCo's Euler does
+static_assert(NG <= 64 && NG >= NB && (CONDIM == 3 || CONDIM == 4) && MAXPAIR % 64 == 0, "sim stage limits");
 constexpr int MAXCHILD = 6;
 constexpr int WAVE = 64;
 
@@ -91,19 +96,22 @@ struct DevModel {
   T mj_act_kp[NA], mj_act_kv[NA];
   int mj_ctrl_qidx[NA];
   int tsid2sim[NA]; // inverse map: TSID actuated joint -> sim joint/actuator index
-  int hull_adr[NB + 1];
-  T rbound[NB][4];
+  int geom_body[NG];   // body carrying each collision geom
+  int hull_adr[NG + 1];
+  T rbound[NG][4];
+  T mj_damping[NV];    // joint damping (passive force -b v; robot/v0/robot.xml:3)
+  T act_range[NA][4];  // control range lo / hi, force range lo / hi of each position actuator (+-1e300 = none)
   T opt[7];
-  T contact[8];
+  T contact[12];       // sliding friction, solref (2), solimp (5), condim, torsional friction, margin, spare
   T meaninertia;
   const T *hull_x, *hull_y, *hull_z; // hull vertices, body frame, struct-of-arrays [nvert] each (device)
-  int chunk_adr[NB + 1];             // 64-vertex spatial chunks per hull (k-d order) ...
+  int chunk_adr[NG + 1];             // 64-vertex spatial chunks per hull (k-d order) ...
   const T *chunk_box;                // ... with boxes [nchunk][6] = centre xyz, half extent xyz (device)
   const int *hull_eadr, *hull_edge;
   // robot<->robot collision: candidate body pairs (after excludes and the parent-child filter), the hulls'
   // centres of mass and body-frame bounding boxes (centre, half extents)
-  int npair, pair_a[MAXPAIR], pair_b[MAXPAIR];
-  T hcen[NB][3], hbox[NB][6];
+  int npair, pair_a[MAXPAIR], pair_b[MAXPAIR]; // geom pairs
+  T hcen[NG][3], hbox[NG][6];
 };
 
 // ------------------------------------------------------------------ small vector helpers

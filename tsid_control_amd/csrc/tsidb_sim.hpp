@@ -36,10 +36,12 @@ struct SimLds {
       T hn[MAXHH][3];   // robot<->robot contacts: normal (geom1 -> geom2); written by the narrow phase
       int hb1[MAXHH];   //                        body of geom1
     };
-    struct {            // collision-time scratch, overlays K only
+    struct {            // collision-time scratch over K.  fcand is read while the narrow phase writes hn / hb1 and
+                        // must stay inside K (asserted below); the rest is dead by then and may reach past it
+      int fcand[64];    // candidate pairs that passed the sphere and the box test: the narrow phase's work list
+      int pcand[128];   // candidate pairs that passed the bounding-sphere test (a batch list)
       T terr[20];       // stepped-terrain table of this env
-      int pcand[64];    // candidate pairs that passed the bounding-sphere test / the mid phase
-      T scen[NB][4];    // bounding spheres in the world (relative to O): centre, radius
+      T scen[NG][4];    // bounding spheres of the geoms in the world (relative to O): centre, radius
     };
   };
   T M[NV * LDM];
@@ -51,10 +53,12 @@ struct SimLds {
   };
   T qpos[NQ], qvel[NV];
   T xv[NV];
-  int cbody[MAXCON], cvert[MAXCON];
+  int cbody[MAXCON], cvert[MAXCON], cgeom[MAXCON]; // contact: body and geom of the hull (geom2), hull vertex
+  T ctq[CONDIM > 3 ? MAXCON : 1][3]; // contact torque vector about the contact point (torsional friction rows)
   unsigned anc[NB]; // ancestor bitmask per body (copied from the model: LDS latency, not global)
   T cr[MAXCON][3], cdist[MAXCON], cfv[MAXCON][3]; // contact point (rel O), distance, force vector
 };
+static_assert(64 * sizeof(int) <= sizeof(float) * NB * 21, "the narrow phase's work list must not reach the contact normals");
 
 __device__ __forceinline__ int sym_idx(int i, int j) { // packed upper index of a symmetric 6x6
   const int a = i < j ? i : j, b = i < j ? j : i;
@@ -161,6 +165,8 @@ __device__ __forceinline__ int contact_frame(const SimLds<T> &L, int c, int nfl,
 template <typename T>
 __device__ __forceinline__ void contact_rows(const DevModel<T> &m, const SimLds<T> &L, int nfl, int c, const T *x,
                                              T mu, T *out) {
+  // rows 0..3: normal +- mu * tangent_k (sliding friction); CONDIM 4 adds rows 4, 5: normal +- mu_t * (relative
+  // angular velocity about the normal) - torsional friction (robot/v0/robot.xml:4)
   T n[3], t1[3], t2[3];
   const int b1 = contact_frame(L, c, nfl, n, t1, t2);
   T tw[6] = {0, 0, 0, 0, 0, 0};
@@ -189,6 +195,10 @@ __device__ __forceinline__ void contact_rows(const DevModel<T> &m, const SimLds<
   const T u[3] = {tw[0] + wxr[0], tw[1] + wxr[1], tw[2] + wxr[2]};
   const T un = dot3(n, u), u1 = dot3(t1, u), u2 = dot3(t2, u);
   out[0] = un + mu * u1; out[1] = un - mu * u1; out[2] = un + mu * u2; out[3] = un - mu * u2;
+  if constexpr (CONDIM > 3) {
+    const T ut = m.contact[9] * dot3(n, tw + 3);
+    out[4] = un + ut; out[5] = un - ut;
+  }
 }
 
 // ------------------------------------------------------------------ collision helpers
@@ -201,7 +211,7 @@ template <typename T> __device__ __forceinline__ T terrain_h(const T *terr, T X,
   return terr[4 + cell];
 }
 
-// Lowest-index vertex of body b's hull within `tie` of the minimum of  r . v + pz  [- terrain height under the
+// Lowest-index vertex of geom b's hull within `tie` of the minimum of  r . v + pz  [- terrain height under the
 // vertex], v in the body frame.  Exact pruned search: the hull's vertices are stored in k-d order, 64 per chunk,
 // each chunk with a bounding box; a chunk can hold the minimum (or a vertex within the tie tolerance of it) only
 // if its lower bound does not exceed the best value found so far, and every such chunk is scanned, so the result
@@ -324,13 +334,15 @@ template <typename T> __device__ __forceinline__ T origin_tri_closest(const T *a
 // support searches per step (hull_argmin: chunk bounds on the lanes, then 64 vertices per scan).
 // Placements L.R / L.p are relative to the base origin O; so is pos.  Returns true with depth >= 0, unit dir
 // (geom1 -> geom2) and pos.
+// a, b: geom indices; their hulls are placed by the bodies that carry them.  margin > 0 (robot/v0/robot.xml:4): each
+// hull is inflated by margin / 2 along the support direction (as mjc_Convex does), the caller takes dist = margin - depth.
 template <typename T>
-__device__ __forceinline__ bool mpr_penetration(const DevModel<T> &m, const SimLds<T> &L, int lane, int a, int b, T &depth, T *dir_out, T *pos) {
+__device__ __forceinline__ bool mpr_penetration(const DevModel<T> &m, const SimLds<T> &L, int lane, int a, int b, T margin, T &depth, T *dir_out, T *pos) {
   const T TOL = sizeof(T) == 8 ? T(1e-10) : T(2e-6), TIE = sizeof(T) == 8 ? T(1e-12) : T(1e-7);
   const T TINY2 = sizeof(T) == 8 ? T(1e-30) : T(1e-20), SIDE = sizeof(T) == 8 ? T(1e-14) : T(1e-9);
   constexpr int MAXIT = 64;
-  const T *Ra = L.R[a], *Rb = L.R[b], *pa = L.p[a], *pb = L.p[b];
-  const int va0 = m.hull_adr[a], vb0 = m.hull_adr[b];
+  const int ba = m.geom_body[a], bb = m.geom_body[b];
+  const T *Ra = L.R[ba], *Rb = L.R[bb], *pa = L.p[ba], *pb = L.p[bb];
   auto wvert = [&](const T *R, const T *p, int i, T *w) {
     const T v[3] = {m.hull_x[i], m.hull_y[i], m.hull_z[i]};
     mat3vec(R, v, w);
@@ -346,6 +358,9 @@ __device__ __forceinline__ bool mpr_penetration(const DevModel<T> &m, const SimL
     wvert(Ra, pa, ia, wa);
     wvert(Rb, pb, ib, wb);
     v[0] = wa[0] - wb[0]; v[1] = wa[1] - wb[1]; v[2] = wa[2] - wb[2];
+    if (margin != 0) { // both hulls inflated by margin / 2 along d (d is a unit vector wherever support is called)
+      v[0] += margin * d[0]; v[1] += margin * d[1]; v[2] += margin * d[2];
+    }
   };
   T ca[3], cb[3], v0[3], v1[3], v2[3], v3[3], v4[3], dir[3], e1[3], e2[3];
   int i1a = 0, i1b = 0, i2a = 0, i2b = 0, i3a = 0, i3b = 0, i4a = 0, i4b = 0;
@@ -498,27 +513,28 @@ __device__ __forceinline__ bool mpr_penetration(const DevModel<T> &m, const SimL
   for (int i = 0; i < 3; i++) { p1[i] += bw[3] * wa[i]; p2[i] += bw[3] * wb[i]; }
 #pragma unroll
   for (int i = 0; i < 3; i++) pos[i] = T(0.5) * (p1[i] + p2[i]) / sum;
-  (void)va0; (void)vb0;
   return true;
 }
 
 // mid phase for one candidate pair (one lane per pair): bounding spheres, then the 15-axis separating-axis test
 // on the hulls' body-frame boxes
 template <typename T>
-__device__ __forceinline__ bool spheres_overlap(const SimLds<T> &L, int a, int b) {
+__device__ __forceinline__ bool spheres_overlap(const SimLds<T> &L, int a, int b, T margin) {
   const T d[3] = {L.scen[a][0] - L.scen[b][0], L.scen[a][1] - L.scen[b][1], L.scen[a][2] - L.scen[b][2]};
-  const T rr = L.scen[a][3] + L.scen[b][3];
+  const T rr = L.scen[a][3] + L.scen[b][3] + margin;
   return !(dot3(d, d) > rr * rr);
 }
 template <typename T>
-__device__ __forceinline__ bool boxes_may_touch(const DevModel<T> &m, const SimLds<T> &L, int a, int b) {
-  const T *Ra = L.R[a], *Rb = L.R[b];
+__device__ __forceinline__ bool boxes_may_touch(const DevModel<T> &m, const SimLds<T> &L, int a, int b, T margin) {
+  const int ba = m.geom_body[a], bb = m.geom_body[b]; // a, b: geoms
+  const T *Ra = L.R[ba], *Rb = L.R[bb];
   T ca[3], cb[3], d[3];
   mat3vec(Ra, m.hbox[a], ca);
   mat3vec(Rb, m.hbox[b], cb);
 #pragma unroll
-  for (int i = 0; i < 3; i++) d[i] = (cb[i] + L.p[b][i]) - (ca[i] + L.p[a][i]);
-  const T *ha = m.hbox[a] + 3, *hb = m.hbox[b] + 3;
+  for (int i = 0; i < 3; i++) d[i] = (cb[i] + L.p[bb][i]) - (ca[i] + L.p[ba][i]);
+  const T hm = T(0.5) * margin; // contacts are made within the margin: both boxes grow by half of it
+  const T ha[3] = {m.hbox[a][3] + hm, m.hbox[a][4] + hm, m.hbox[a][5] + hm}, hb[3] = {m.hbox[b][3] + hm, m.hbox[b][4] + hm, m.hbox[b][5] + hm};
   T Rm[3][3], A[3][3], t[3];
 #pragma unroll
   for (int i = 0; i < 3; i++) {
@@ -556,7 +572,7 @@ struct RowState {
   T fD, fR, floss, faref, fjar, fJv;
   // contact rows
   bool has_c;
-  T cD, caref[4], cjar[4], cJv[4];
+  T cD, caref[NROWC], cjar[NROWC], cJv[NROWC];
 };
 
 // cost / first / second derivative contribution of this lane's rows at jar + alpha*Jv
@@ -571,7 +587,7 @@ __device__ __forceinline__ void rows_eval(const RowState<T> &rs, T alpha, T &c, 
   }
   if (rs.has_c) {
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
+    for (int i = 0; i < NROWC; i++) {
       const T x = rs.cjar[i] + alpha * rs.cJv[i];
       if (x < 0) { c += T(0.5) * rs.cD * x * x; g += rs.cD * x * rs.cJv[i]; h += rs.cD * rs.cJv[i] * rs.cJv[i]; }
     }
@@ -772,16 +788,22 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
   if (lane < NA) {
     const int d = m.mj_act_dof[lane];
     // closed loop: TSID's joint torques as motor forces; otherwise the reference's position servos
-    L.xv[d] = motor_tau ? motor_tau[m.mj_ctrl_qidx[lane] - 7]
-                        : m.mj_act_kp[lane] * (myctrl - L.qpos[d + 1]) - m.mj_act_kv[lane] * L.qvel[d];
+    // position servo kp (ctrl - q) - kv qdot with the control clamped to its range and the force to its range
+    // (robot/v0/robot.xml:5 ctrlrange / forcerange; the v1 robot has neither: +-1e300)
+    const T cc = myctrl < m.act_range[lane][0] ? m.act_range[lane][0] : (myctrl > m.act_range[lane][1] ? m.act_range[lane][1] : myctrl);
+    T servo = m.mj_act_kp[lane] * (cc - L.qpos[d + 1]) - m.mj_act_kv[lane] * L.qvel[d];
+    servo = servo < m.act_range[lane][2] ? m.act_range[lane][2] : (servo > m.act_range[lane][3] ? m.act_range[lane][3] : servo);
+    L.xv[d] = motor_tau ? motor_tau[m.mj_ctrl_qidx[lane] - 7] : servo;
   } else if (lane >= 32 && lane < 38) L.xv[lane - 32] = 0;
   __syncthreads();
   if (lane < NV) qfs += L.xv[lane];
-  // ---- floor collision, first half: bounding-sphere pretest for all bodies at once (lane = body, whose rotation and
-  //      position are still in this lane's registers).  Done BEFORE the factorisation below so that the placement
-  //      registers are dead during it (they were what spilled there); only the bodies that can reach the floor
-  //      enter the support search later, in body order
-  const T margin = 0, tie_tol = m.opt[6];
+  if constexpr (EULERDAMP) { // passive joint damping (robot/v0/robot.xml:3)
+    if (lane < NV) qfs -= m.mj_damping[lane] * L.qvel[lane];
+  }
+  // ---- floor collision, first half: bounding-sphere pretest for all geoms at once (lane = geom, placed by its body).
+  //      Done BEFORE the factorisation below (nothing of it stays live across it); only the geoms that can reach the
+  //      floor enter the support search later, in geom order
+  const T margin = m.contact[10], tie_tol = m.opt[6];
   const T Ow[3] = {L.qpos[0], L.qpos[1], L.qpos[2]};
   const T nO = dot3(fl.n, Ow) - fl.d; // signed distance of the base origin O to the floor plane
 #ifdef TSIDB_NO_TERR
@@ -794,18 +816,20 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
 #pragma unroll
     for (int i = 0; i < 16; i++) hmax_all = terr_g[4 + i] > hmax_all ? terr_g[4 + i] : hmax_all;
   }
-  unsigned long long cand_bodies;
+  unsigned long long cand_geoms;
   {
     bool near = false;
-    if (lane < NB) {
-      const T c6 = fl.n[0] * Rb[0] + fl.n[1] * Rb[3] + fl.n[2] * Rb[6];
-      const T c7 = fl.n[0] * Rb[1] + fl.n[1] * Rb[4] + fl.n[2] * Rb[7];
-      const T c8 = fl.n[0] * Rb[2] + fl.n[1] * Rb[5] + fl.n[2] * Rb[8];
-      const T pzl = dot3(fl.n, pb) + nO;
+    if (lane < NG) {
+      const int gb = m.geom_body[lane];
+      const T *Rg = L.R[gb];
+      const T c6 = fl.n[0] * Rg[0] + fl.n[1] * Rg[3] + fl.n[2] * Rg[6];
+      const T c7 = fl.n[0] * Rg[1] + fl.n[1] * Rg[4] + fl.n[2] * Rg[7];
+      const T c8 = fl.n[0] * Rg[2] + fl.n[1] * Rg[5] + fl.n[2] * Rg[8];
+      const T pzl = dot3(fl.n, L.p[gb]) + nO;
       const T zc = c6 * m.rbound[lane][0] + c7 * m.rbound[lane][1] + c8 * m.rbound[lane][2] + pzl;
       near = !(zc - m.rbound[lane][3] - hmax_all > margin);
     }
-    cand_bodies = __ballot(near);
+    cand_geoms = __ballot(near);
   }
   TSIDB_STAMP(17);
   // ---- qacc_smooth = M^-1 qfrc_smooth
@@ -827,19 +851,19 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
     __syncthreads();
   }
   int ncon = 0;
-  for (unsigned long long bm = cand_bodies; bm && ncon < MAXCON; bm &= bm - 1) {
-    const int b = __ffsll((long long)bm) - 1;
+  for (unsigned long long bm = cand_geoms; bm && ncon < MAXCON; bm &= bm - 1) {
+    const int g = __ffsll((long long)bm) - 1, b = m.geom_body[g];
     const T *Rb = L.R[b];
     // floor normal in the body frame; "z" below = signed distance to the floor
     const T r6 = fl.n[0] * Rb[0] + fl.n[1] * Rb[3] + fl.n[2] * Rb[6];
     const T r7 = fl.n[0] * Rb[1] + fl.n[1] * Rb[4] + fl.n[2] * Rb[7];
     const T r8 = fl.n[0] * Rb[2] + fl.n[1] * Rb[5] + fl.n[2] * Rb[8];
     const T pz = dot3(fl.n, L.p[b]) + nO;
-    const int v0 = m.hull_adr[b];
+    const int v0 = m.hull_adr[g];
     T zmin;
-    const int best = has_terr ? hull_argmin<T, true>(m, lane, b, r6, r7, r8, pz, tie_tol, L.terr, Rb, L.p[b][0] + Ow[0],
+    const int best = has_terr ? hull_argmin<T, true>(m, lane, g, r6, r7, r8, pz, tie_tol, L.terr, Rb, L.p[b][0] + Ow[0],
                                                      L.p[b][1] + Ow[1], hmax_all, zmin)
-                              : hull_argmin<T, false>(m, lane, b, r6, r7, r8, pz, tie_tol, nullptr, nullptr, T(0), T(0), T(0), zmin);
+                              : hull_argmin<T, false>(m, lane, g, r6, r7, r8, pz, tie_tol, nullptr, nullptr, T(0), T(0), T(0), zmin);
     if (zmin > margin) continue;
     // the support vertex, then its hull-graph neighbours within the margin
     const int e0 = m.hull_eadr[best];
@@ -862,6 +886,7 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
     if (keep && slot < MAXCON) {
       const T dist = wd;
       L.cbody[slot] = b;
+      L.cgeom[slot] = g;
       L.cvert[slot] = vid - v0;
       L.cdist[slot] = dist;
 #pragma unroll
@@ -877,47 +902,57 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
 #ifndef TSIDB_NO_HH
   if (m.params[P_SELF_COLLISION] != 0) {
     // bounding spheres of all bodies in the world (lane = body)
-    if (lane < NB) { // (placements from LDS: keeping this lane's copy in registers across the floor search spills)
+    if (lane < NG) {
+      const int gb = m.geom_body[lane];
       T c[3];
-      mat3vec(L.R[lane], m.rbound[lane], c);
-      L.scen[lane][0] = c[0] + L.p[lane][0]; L.scen[lane][1] = c[1] + L.p[lane][1]; L.scen[lane][2] = c[2] + L.p[lane][2];
+      mat3vec(L.R[gb], m.rbound[lane], c);
+      L.scen[lane][0] = c[0] + L.p[gb][0]; L.scen[lane][1] = c[1] + L.p[gb][1]; L.scen[lane][2] = c[2] + L.p[gb][2];
       L.scen[lane][3] = m.rbound[lane][3];
     }
     __syncthreads();
-    // broad phase, one lane per pair: sphere test, survivors compacted; then the box test once on the survivors
-    int nsph = 0;
+    // broad phase, one lane per pair: sphere test, survivors compacted into a list; the box test then runs on the list
+    // 64 entries at a time (once, at the end, for the v1 robot's ~30 survivors; the v0 robot has 1044 pairs)
+    int nsph = 0, ncand = 0;
     bool over = false;
+    auto box_pass = [&](int cnt) { // pcand[0, cnt) -> survivors appended to fcand, in pair order
+      const int k = lane < cnt ? L.pcand[lane] : 0;
+      const bool may = lane < cnt && boxes_may_touch(m, L, m.pair_a[k], m.pair_b[k], margin);
+      const unsigned long long mk = __ballot(may);
+      const int pos = ncand + __popcll(mk & ((1ull << lane) - 1ull));
+      if (may && pos < WAVE) L.fcand[pos] = k;
+      ncand += __popcll(mk);
+    };
     for (int k0 = 0; k0 < m.npair; k0 += WAVE) {
       const int k = k0 + lane;
-      const bool may = k < m.npair && spheres_overlap(L, m.pair_a[k], m.pair_b[k]);
+      const bool may = k < m.npair && spheres_overlap(L, m.pair_a[k], m.pair_b[k], margin);
       const unsigned long long mk = __ballot(may);
-      const int pos = nsph + __popcll(mk & ((1ull << lane) - 1ull));
-      if (may && pos < WAVE) L.pcand[pos] = k;
+      if (may) L.pcand[nsph + __popcll(mk & ((1ull << lane) - 1ull))] = k; // nsph <= 64 here: the list holds 128
       nsph += __popcll(mk);
+      if (nsph > WAVE) {
+        __syncthreads();
+        box_pass(WAVE);
+        const int rest = lane < nsph - WAVE ? L.pcand[WAVE + lane] : 0;
+        __syncthreads();
+        if (lane < nsph - WAVE) L.pcand[lane] = rest;
+        nsph -= WAVE;
+        __syncthreads();
+      }
     }
-    if (nsph > WAVE) { nsph = WAVE; over = true; }
     __syncthreads();
-    int ncand = 0;
-    {
-      const int k = lane < nsph ? L.pcand[lane] : 0;
-      const bool may = lane < nsph && boxes_may_touch(m, L, m.pair_a[k], m.pair_b[k]);
-      const unsigned long long mk = __ballot(may);
-      const int pos = __popcll(mk & ((1ull << lane) - 1ull));
-      __syncthreads();
-      if (may) L.pcand[pos] = k; // in pair order: ballot positions preserve it
-      ncand = __popcll(mk);
-    }
+    box_pass(nsph);
+    if (ncand > WAVE) { ncand = WAVE; over = true; }
     __syncthreads();
     for (int ci = 0; ci < ncand; ci++) {
-      const int k = L.pcand[ci];
-      const int a = m.pair_a[k], b = m.pair_b[k];
+      const int k = L.fcand[ci];
+      const int ga = m.pair_a[k], gb = m.pair_b[k], a = m.geom_body[ga], b = m.geom_body[gb]; // geoms, their bodies
       T depth, dir[3], pos[3];
-      if (!mpr_penetration(m, L, lane, a, b, depth, dir, pos)) continue;
+      if (!mpr_penetration(m, L, lane, ga, gb, margin, depth, dir, pos)) continue;
       if (ncon - nfl >= MAXHH || ncon >= MAXCON) { over = true; continue; }
       if (lane == 0) {
         L.cbody[ncon] = b;
-        L.cvert[ncon] = 0x8000 | a;
-        L.cdist[ncon] = -depth;
+        L.cgeom[ncon] = gb;
+        L.cvert[ncon] = 0x8000 | ga;
+        L.cdist[ncon] = margin - depth;
         L.hb1[ncon - nfl] = a;
 #pragma unroll
         for (int i = 0; i < 3; i++) { L.cr[ncon][i] = pos[i]; L.hn[ncon - nfl][i] = dir[i]; }
@@ -933,7 +968,7 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
   qfs = lane < NV ? park[NV + lane] : T(0);
   asm volatile("" ::"v"(qas), "v"(qfs)); // (the reload is the definition the rest of the kernel uses)
   if (lane == 0 && ncon_out) ncon_out[0] = ncon;
-  if (con_out && lane < MAXCON) con_out[lane] = lane < ncon ? ((L.cbody[lane] << 16) | L.cvert[lane]) : -1;
+  if (con_out && lane < MAXCON) con_out[lane] = lane < ncon ? ((L.cgeom[lane] << 16) | L.cvert[lane]) : -1;
 
   TSIDB_STAMP(19);
   // ---- constraint rows: frictionloss (lane = dof), pyramidal contact rows (lane = contact)
@@ -946,6 +981,8 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
   const T timeconst = m.contact[1] > 2 * dt ? m.contact[1] : 2 * dt, dampratio = m.contact[2];
   const T dmin = m.contact[3], dmax = m.contact[4], width = m.contact[5], mid = m.contact[6], power = m.contact[7];
   const T kk = T(1) / (dmax * dmax * timeconst * timeconst * dampratio * dampratio), bb = T(2) / (dmax * timeconst);
+  // frictionloss rows take the joint's solreffriction, which neither MJCF sets: MuJoCo's default (0.02, 1)
+  const T tcf = T(0.02) > 2 * dt ? T(0.02) : 2 * dt, bbf = T(2) / (dmax * tcf);
   RowState<T> rs;
   rs.has_f = lane < NV && m.mj_frictionloss[lane < NV ? lane : 0] > 0;
   rs.fD = rs.fR = rs.floss = rs.faref = rs.fjar = rs.fJv = 0;
@@ -954,12 +991,12 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
     rs.fR = r > MINVAL ? r : MINVAL;
     rs.fD = T(1) / rs.fR;
     rs.floss = m.mj_frictionloss[lane];
-    rs.faref = -bb * L.qvel[lane];
+    rs.faref = -bbf * L.qvel[lane];
   }
   rs.has_c = lane < ncon;
   rs.cD = 0;
 #pragma unroll
-  for (int i = 0; i < 4; i++) rs.caref[i] = rs.cjar[i] = rs.cJv[i] = 0;
+  for (int i = 0; i < NROWC; i++) rs.caref[i] = rs.cjar[i] = rs.cJv[i] = 0;
   if (rs.has_c) {
     const int c = lane;
     const T dist = L.cdist[c];
@@ -981,31 +1018,32 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
     T R0 = (1 - imp) / imp * diagA;
     R0 = R0 > MINVAL ? R0 : MINVAL;
     rs.cD = T(1) / (2 * mu * mu * R0);
-    T vel[4];
+    T vel[NROWC];
     contact_rows(m, L, nfl, c, L.qvel, mu, vel);
 #pragma unroll
-    for (int i = 0; i < 4; i++) rs.caref[i] = -bb * vel[i] - kk * imp * (dist - margin);
+    for (int i = 0; i < NROWC; i++) rs.caref[i] = -bb * vel[i] - kk * imp * (dist - margin);
   }
 
   int solver_iter = 0;
   T qacc = qas;
-  const int nefc = NA + 4 * ncon; // frictionloss rows exist on all hinges
+  const int nefc = NA + NROWC * ncon; // frictionloss rows exist on all hinges
+  T Ma = 0; // M qacc at the current point
   if (nefc > 0) {
     // helpers over a candidate qacc held per lane (value `xa`, also staged in L.xv)
     auto stage = [&](T xa) { __syncthreads(); if (lane < NV) L.xv[lane] = xa; __syncthreads(); };
     auto jar_of = [&](T xa) { // fills rs.fjar / rs.cjar from L.xv
       if (rs.has_f) rs.fjar = xa - rs.faref;
       if (rs.has_c) {
-        T o[4];
+        T o[NROWC];
         contact_rows(m, L, nfl, lane, L.xv, mu, o);
 #pragma unroll
-        for (int i = 0; i < 4; i++) rs.cjar[i] = o[i] - rs.caref[i];
+        for (int i = 0; i < NROWC; i++) rs.cjar[i] = o[i] - rs.caref[i];
       }
     };
     // warm start: keep qacc_warmstart only if it is cheaper than qacc_smooth
     T xw = lane < NV ? qacc_ws_g[lane] : T(0);
     stage(xw);
-    T Ma = mulM(L, L.xv, lane);
+    Ma = mulM(L, L.xv, lane);
     jar_of(xw);
     T cc, gg, hh;
     rows_eval(rs, T(0), cc, gg, hh);
@@ -1013,9 +1051,9 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
     // keep the warm start's row residuals while the smooth solution is evaluated: whichever wins, its
     // M a and residuals are already there (same operations on the same data as evaluating the winner again)
     const T fjar_w = rs.fjar;
-    T cjar_w[4];
+    T cjar_w[NROWC];
 #pragma unroll
-    for (int i = 0; i < 4; i++) cjar_w[i] = rs.cjar[i];
+    for (int i = 0; i < NROWC; i++) cjar_w[i] = rs.cjar[i];
     stage(qas);
     jar_of(qas);
     rows_eval(rs, T(0), cc, gg, hh);
@@ -1027,7 +1065,7 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
       qacc = xw;
       rs.fjar = fjar_w;
 #pragma unroll
-      for (int i = 0; i < 4; i++) rs.cjar[i] = cjar_w[i];
+      for (int i = 0; i < NROWC; i++) rs.cjar[i] = cjar_w[i];
     }
 
     TSIDB_STAMP(20);
@@ -1054,17 +1092,27 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
         else { ff = -rs.fD * rs.fjar; fact = true; }
       }
       T Arow[6] = {0, 0, 0, 0, 0, 0}; // sum_rows D dir dir^T (sym 3x3: xx xy xz yy yz zz)
+      T tors_e = 0, tors_f = 0;      // CONDIM 4: mu_t (D4 - D5), mu_t^2 (D4 + D5) over the active torsional rows
       if (rs.has_c) {
-        T fr[4];
+        T fr[NROWC];
         T fv[3] = {0, 0, 0};
         T cn[3], ct1[3], ct2[3];
         contact_frame(L, lane, nfl, cn, ct1, ct2);
+        if constexpr (CONDIM > 3) { // torsional rows: force along the normal, torque +- mu_t * force about it
+          const T mut = m.contact[9];
+          const bool a4 = rs.cjar[4] < 0, a5 = rs.cjar[5] < 0;
+          const T f4 = a4 ? -rs.cD * rs.cjar[4] : T(0), f5 = a5 ? -rs.cD * rs.cjar[5] : T(0);
+          const T tq = mut * (f4 - f5);
+          L.ctq[lane][0] = tq * cn[0]; L.ctq[lane][1] = tq * cn[1]; L.ctq[lane][2] = tq * cn[2];
+          tors_e = mut * ((a4 ? rs.cD : T(0)) - (a5 ? rs.cD : T(0)));
+          tors_f = mut * mut * ((a4 ? rs.cD : T(0)) + (a5 ? rs.cD : T(0)));
+        }
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
+        for (int i = 0; i < NROWC; i++) {
           const bool act = rs.cjar[i] < 0;
           fr[i] = act ? -rs.cD * rs.cjar[i] : T(0);
-          // direction of row i in world axes: n + s*mu*t_k
-          const T sg = (i & 1) ? -mu : mu;
+          // direction of row i in world axes: n + s*mu*t_k (sliding rows), n (torsional rows)
+          const T sg = i >= 4 ? T(0) : ((i & 1) ? -mu : mu);
           const T *tk = i < 2 ? ct1 : ct2;
           const T dir[3] = {cn[0] + sg * tk[0], cn[1] + sg * tk[1], cn[2] + sg * tk[2]};
 #pragma unroll
@@ -1089,6 +1137,7 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
           if (sgn == 0) continue;
           T rxf[3];
           cross3(L.cr[c], L.cfv[c], rxf);
+          if constexpr (CONDIM > 3) { rxf[0] += L.ctq[c][0]; rxf[1] += L.ctq[c][1]; rxf[2] += L.ctq[c][2]; }
           const T js = L.S[k][0] * L.cfv[c][0] + L.S[k][1] * L.cfv[c][1] + L.S[k][2] * L.cfv[c][2] +
                        L.S[k][3] * rxf[0] + L.S[k][4] * rxf[1] + L.S[k][5] * rxf[2];
           s += sgn > 0 ? js : -js;
@@ -1126,6 +1175,20 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
         for (int i = 0; i < 3; i++)
 #pragma unroll
           for (int j = 0; j < 3; j++) L.Wc[lane][sym_idx(i, 3 + j)] = XA[3 * j + i];
+        if constexpr (CONDIM > 3) {
+          // torsional rows w = [n; r x n +- mu_t n]: on top of the above, e n n^T in the lin-ang block and
+          // e ((r x n) n^T + n (r x n)^T) + f n n^T in the ang-ang block
+          T cn[3], ct1[3], ct2[3], xn[3];
+          contact_frame(L, lane, nfl, cn, ct1, ct2);
+          cross3(r, cn, xn);
+#pragma unroll
+          for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+              L.Wc[lane][sym_idx(i, 3 + j)] += tors_e * cn[i] * cn[j];
+              if (j >= i) L.Wc[lane][sym_idx(3 + i, 3 + j)] += tors_e * (xn[i] * cn[j] + cn[i] * xn[j]) + tors_f * cn[i] * cn[j];
+            }
+        }
       }
       for (int i = lane; i < NB * 21; i += WAVE) (&L.K[0][0])[i] = 0;
       __syncthreads();
@@ -1194,15 +1257,25 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
 #pragma unroll
             for (int i = 0; i < 3; i++) jk[i] = sgn > 0 ? L.S[lane][i] + wxr[i] : -(L.S[lane][i] + wxr[i]);
           }
-          T *g = &L.K[0][0] + 3 * lane;
+          T *g = &L.K[0][0] + 5 * lane;
           g[0] = A6[0] * jk[0] + A6[1] * jk[1] + A6[2] * jk[2];
           g[1] = A6[1] * jk[0] + A6[3] * jk[1] + A6[4] * jk[2];
           g[2] = A6[2] * jk[0] + A6[4] * jk[1] + A6[5] * jk[2];
+          if constexpr (CONDIM > 3) { // a_k = n . j_k (relative linear), b_k = n . (relative angular) for the torsional rows
+            const T *hn = L.hn[c - nfl];
+            g[3] = hn[0] * jk[0] + hn[1] * jk[1] + hn[2] * jk[2];
+            g[4] = sgn == 0 ? T(0) : (sgn > 0 ? T(1) : T(-1)) * (hn[0] * L.S[lane][3] + hn[1] * L.S[lane][4] + hn[2] * L.S[lane][5]);
+          }
         }
         __syncthreads();
+        const T te = rdlane_dyn(tors_e, c), tf = rdlane_dyn(tors_f, c);
         if (lane < NV) {
           const T *g = &L.K[0][0];
-          for (int k = 0; k < NV; k++) L.H[lane * LDM + k] += jk[0] * g[3 * k] + jk[1] * g[3 * k + 1] + jk[2] * g[3 * k + 2];
+          for (int k = 0; k < NV; k++) L.H[lane * LDM + k] += jk[0] * g[5 * k] + jk[1] * g[5 * k + 1] + jk[2] * g[5 * k + 2];
+          if constexpr (CONDIM > 3) {
+            const T ai = g[5 * lane + 3], bi = g[5 * lane + 4];
+            for (int k = 0; k < NV; k++) L.H[lane * LDM + k] += te * (ai * g[5 * k + 4] + bi * g[5 * k + 3]) + tf * bi * g[5 * k + 4];
+          }
         }
         __syncthreads();
       }
@@ -1254,7 +1327,7 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
       if (rs.has_f) rs.fjar += alpha * rs.fJv;
       if (rs.has_c) {
 #pragma unroll
-        for (int i = 0; i < 4; i++) rs.cjar[i] += alpha * rs.cJv[i];
+        for (int i = 0; i < NROWC; i++) rs.cjar[i] += alpha * rs.cJv[i];
       }
       iter++;
       TSIDB_LAP(27);
@@ -1266,8 +1339,20 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
   // ---- semi-implicit Euler, write back
   asm volatile("" ::: "memory");
   const T dte = m.opt[0];
+  T qacc_int = qacc; // the acceleration the velocity is advanced with
+  if constexpr (EULERDAMP) {
+    // MuJoCo's Euler integrates joint damping implicitly: v+ = v + h (M + h B)^-1 (M qacc), with M qacc = the total
+    // force the solver ended on (tracked in Ma); qacc itself (reported, warm start) stays the solver's
+    T Mq = Ma;
+    if (nefc == 0) { __syncthreads(); if (lane < NV) L.xv[lane] = qacc; __syncthreads(); Mq = mulM(L, L.xv, lane); }
+#pragma unroll
+    for (int j = 0; j < NV; j++) arow[j] = lane < NV ? L.M[lane * LDM + j] + (j == lane ? dte * m.mj_damping[j] : T(0)) : T(0);
+    bool okd;
+    qacc_int = chol26_solve<T, false>(arow, Mq, lane, okd);
+    if (!okd) fail |= 1;
+  }
   if (lane < NV) {
-    const T vn = L.qvel[lane] + dte * qacc;
+    const T vn = L.qvel[lane] + dte * qacc_int;
     L.qvel[lane] = vn;
     qvel_g[lane] = vn;
     qacc_ws_g[lane] = qacc;

@@ -436,6 +436,11 @@ def compile_model(ref_root: Path, out: Path):
     frame_names = ["left_sole_joint_fixed", "right_sole_joint_fixed"]  # ctrl/conf.py:17-18
     ts = build_tsid_model(v1 / "urdf" / "robot_mod.urdf", v1 / "urdf" / "robot.srdf", frame_names)
     sim = build_sim_model(v1 / "mujoco" / "robot.xml", v1 / "mujoco" / "assets")
+    return assemble_blob(ts, sim, out)
+
+
+def assemble_blob(ts, sim, out: Path):
+    """TSID model + sim model -> blob sections (both robots)."""
     c0 = sim_constants_at_qpos0(sim)
     bodies = sim["bodies"]
     nb = len(bodies)
@@ -446,14 +451,26 @@ def compile_model(ref_root: Path, out: Path):
     sim_joint_names = [b["joint"] for b in bodies[1:]]
     sim2tsid = np.array([ts["names"].index(n) - 1 for n in sim_joint_names], np.int32)
 
-    # candidate robot<->robot body pairs: all pairs minus parent-child minus excludes
+    # collision geoms: one per body in the v1 robot (robot.xml:13-15), several in the v0 robot
+    geom_body = np.array([g["body"] for g in sim["geoms"]], np.int32) if "geoms" in sim else np.arange(nb, dtype=np.int32)
+    ng = len(geom_body)
+    # candidate robot<->robot geom pairs: different bodies, minus parent-child, minus excludes (body pairs)
     exc = {tuple(sorted(map(int, e))) for e in sim["excl"]}
-    pairs = [(i, j) for i in range(nb) for j in range(i + 1, nb)
-             if bodies[j]["parent"] != i and bodies[i]["parent"] != j and (i, j) not in exc]
+    pairs = [(i, j) for i in range(ng) for j in range(i + 1, ng)
+             if geom_body[i] != geom_body[j] and bodies[geom_body[j]]["parent"] != geom_body[i]
+             and bodies[geom_body[i]]["parent"] != geom_body[j] and tuple(sorted((int(geom_body[i]), int(geom_body[j])))) not in exc]
+    condim = int(sim.get("condim", 3))
+    friction = np.asarray(sim.get("friction", [1.0, 0.005, 0.0001]), dtype=np.float64)
+    solref = np.asarray(sim.get("solref", [0.02, 1.0]), dtype=np.float64)
+    damping = float(sim.get("damping", 0.0))
+    nv = 6 + nb - 1
+    big = 1e300
+    cr, fr = sim.get("ctrlrange", (-big, big)), sim.get("forcerange", (-big, big))
 
     sections = {
-        "model_dims": np.array([len(ts["names"]), len(ts["names"]) + 6, len(ts["names"]) + 5, len(ts["names"]) - 1, nb, 1],
-                               np.int32),  # NJ NQ NV NA NB has_sim: which libtsidb build the blob is for
+        # NJ NQ NV NA NB has_sim | NG condim eulerdamp: which libtsidb build the blob is for
+        "model_dims": np.array([len(ts["names"]), len(ts["names"]) + 6, len(ts["names"]) + 5, len(ts["names"]) - 1, nb, 1,
+                                ng, condim, 1 if damping > 0 else 0], np.int32),
         # ---- TSID side
         "pin_parent": ts["parent"], "pin_place": ts["place"], "pin_inertia": ts["inertia"],
         "pin_frame_parent": ts["frame_parent"], "pin_frame_place": ts["frame_place"],
@@ -465,6 +482,9 @@ def compile_model(ref_root: Path, out: Path):
         "mj_inertia": np.array([b["inertia"].pack() for b in bodies]),
         "mj_armature": c0["arm"],
         "mj_frictionloss": np.array([0.0] * 6 + [sim["frictionloss"]] * (nb - 1)),
+        "mj_damping": np.array([0.0] * 6 + [damping] * (nb - 1)),
+        "mj_geom_body": geom_body,
+        "mj_act_range": np.tile(np.array([cr[0], cr[1], fr[0], fr[1]], dtype=np.float64), (len(c0["act_dof"]), 1)),
         "mj_dof_M0": c0["dof_M0"], "mj_dof_invw0": c0["dof_invweight0"],
         "mj_body_invw0": c0["body_invweight0"],
         "mj_act_dof": c0["act_dof"], "mj_act_kp": np.full(len(c0["act_dof"]), sim["kp"]),
@@ -477,13 +497,15 @@ def compile_model(ref_root: Path, out: Path):
         "mj_hull_center": sim["hull_center"], "mj_hull_box": sim["hull_box"],
         # MuJoCo option / contact defaults (no <option>, no geom contact attrs in the MJCF)
         "mj_opt": np.array([0.002, -9.81, 1e-8, 100, 50, 0.01, 1.0]),  # dt gz tol iters ls_iters ls_tol impratio
-        "mj_contact": np.array([1.0, 0.02, 1.0, 0.9, 0.95, 0.001, 0.5, 2.0]),  # mu, solref[2], solimp[5]
+        # mu (sliding), solref[2], solimp[5] (MuJoCo defaults), condim, torsional friction, margin, spare
+        "mj_contact": np.array([friction[0], solref[0], solref[1], 0.9, 0.95, 0.001, 0.5, 2.0, condim, friction[1],
+                                float(sim.get("margin", 0.0)), 0.0]),
     }
     write_blob(out, sections)
     return ts, sim, c0, sections
 
 
-def emit_topology_header(mj_parent, path: Path, nj=None, na=None, has_sim=True):
+def emit_topology_header(mj_parent, path: Path, nj=None, na=None, has_sim=True, ng=None, condim=3, eulerdamp=False, npair=0):
     """Compile-time facts of ONE robot for libtsidb: the dimensions (TSID joints incl. the free-flyer, nq, nv,
     actuated joints, sim bodies) and the sim tree's dof ancestry for the register Cholesky (tree-sparse elimination
     without run-time branches).  One library is built per robot (`-DTSIDB_TOPOLOGY_HEADER=...`); tsidb_create refuses
@@ -517,6 +539,11 @@ def emit_topology_header(mj_parent, path: Path, nj=None, na=None, has_sim=True):
            f"constexpr int TOPO_NJ = {nj}, TOPO_NQ = {nj + 6}, TOPO_NV = {nj + 5}, TOPO_NA = {na};\n"
            f"constexpr int TOPO_HAS_SIM = {1 if has_sim else 0};\n"
            f"constexpr int TOPO_NB = {nb};\n"
+           "// sim stage: collision geoms (convex hulls; several per body are allowed), contact dimension (3: pyramid of 4\n"
+           "// rows, 4: + torsional friction, 6 rows), joint damping integrated implicitly (MuJoCo's Euler), room for the\n"
+           "// candidate geom pairs (a multiple of 64)\n"
+           f"constexpr int TOPO_NG = {nb if ng is None else ng}, TOPO_CONDIM = {condim}, TOPO_EULERDAMP = {1 if eulerdamp else 0}, "
+           f"TOPO_MAXPAIR = {max(64, (npair + 63) // 64 * 64)};\n"
            "constexpr int TOPO_PARENT[] = {" + ", ".join(str(int(x)) for x in mj_parent) + "};\n"
            "constexpr unsigned MJ_DOFANC[] = {" + ", ".join(hex(x) + "u" for x in dofanc) + "};\n"
            "} // namespace tsidb\n")
@@ -539,18 +566,158 @@ def compile_tsid_only(urdf: Path, srdf: Path, frame_names, out: Path):
     return ts, sections
 
 
+# --------------------------------------------------------------------------- general MJCF (the v0 robot)
+def _quat_mul(a, b):
+    w1, x1, y1, z1 = a
+    w2, x2, y2, z2 = b
+    return np.array([w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2, w1 * x2 + x1 * w2 + y1 * z2 - z1 * y2,
+                     w1 * y2 - x1 * z2 + y1 * w2 + z1 * x2, w1 * z2 + x1 * y2 - y1 * x2 + z1 * w2])
+
+
+def R_to_quat_wxyz(R):
+    t = np.trace(R)
+    if t > 0:
+        s = np.sqrt(t + 1.0) * 2
+        q = np.array([0.25 * s, (R[2, 1] - R[1, 2]) / s, (R[0, 2] - R[2, 0]) / s, (R[1, 0] - R[0, 1]) / s])
+    else:
+        i = int(np.argmax(np.diag(R)))
+        j, k = (i + 1) % 3, (i + 2) % 3
+        s = np.sqrt(1.0 + R[i, i] - R[j, j] - R[k, k]) * 2
+        q = np.zeros(4)
+        q[0] = (R[k, j] - R[j, k]) / s
+        q[1 + i] = 0.25 * s
+        q[1 + j] = (R[j, i] + R[i, j]) / s
+        q[1 + k] = (R[k, i] + R[i, k]) / s
+    return q / np.linalg.norm(q)
+
+
+def build_sim_model_mjcf(mjcf: Path, mesh_dir: Path):
+    """Sim side of a robot from a general single-file MJCF (robot/v0/robot.xml): top-level <default> for joints /
+    geoms / position actuators, bodies with several mesh geoms each (every geom whose contype is not 0 collides - in
+    this file that includes the "visual" ones: only the default class itself carries class="visualgeom"), a static
+    child body welded into its parent (root -> torso), hinge axes +-z (a -z hinge is the +z hinge of the body frame
+    turned by pi about x), diaginertia + quat inertials, position actuators with control / force ranges, the ground
+    plane.  Returns the dict build_sim_model returns, plus `geoms` (body, hull) and the contact / actuator extras."""
+    root = ET.parse(mjcf).getroot()
+    dflt = root.find("default")
+    jd, gd, pd = dflt.find("joint"), dflt.find("geom"), dflt.find("position")
+    damping, armature, frictionloss = (float(jd.get(k, "0")) for k in ("damping", "armature", "frictionloss"))
+    g_condim, g_contype = int(gd.get("condim", "3")), int(gd.get("contype", "1"))
+    g_friction = _floats(gd.get("friction", "1 0.005 0.0001"))
+    g_solref = _floats(gd.get("solref", "0.02 1"))
+    g_margin = float(gd.get("margin", "0"))
+    kp = float(pd.get("kp", "1"))
+    ctrlrange, forcerange = _floats(pd.get("ctrlrange", "-1e300 1e300")), _floats(pd.get("forcerange", "-1e300 1e300"))
+    mesh_file = {m.get("name"): m.get("file") for m in root.find("asset").findall("mesh")}
+    Rx = np.diag([1.0, -1.0, -1.0])
+
+    bodies, geoms = [], []
+
+    def inertial_of(b):
+        ine = b.find("inertial")
+        if ine is None:
+            return None
+        Ri = quat_wxyz_to_R(_floats(ine.get("quat", "1 0 0 0")))
+        if ine.get("fullinertia") is not None:
+            fi = _floats(ine.get("fullinertia"))
+            I = sym6_to_mat([fi[0], fi[3], fi[4], fi[1], fi[5], fi[2]])
+        else:
+            I = Ri @ np.diag(_floats(ine.get("diaginertia"))) @ Ri.T
+        return Inertia(float(ine.get("mass")), _floats(ine.get("pos", "0 0 0")), I)
+
+    def walk(elem, parent, Rp, pp):
+        """(Rp, pp): placement, in the carrying body `parent`, of the frame `elem`'s children are expressed in"""
+        for b in elem.findall("body"):
+            R = Rp @ quat_wxyz_to_R(_floats(b.get("quat", "1 0 0 0")))
+            p = Rp @ _floats(b.get("pos", "0 0 0")) + pp
+            jn, fj = b.find("joint"), b.find("freejoint")
+            if jn is None and fj is None:          # static child: welded into the carrying body
+                carrier, Rb, pb = parent, R, p
+            else:
+                flip = False
+                if jn is not None:
+                    ax = _floats(jn.get("axis", "0 0 1"))
+                    assert jn.get("type", "hinge") == "hinge" and np.allclose(np.abs(ax), [0, 0, 1]), "z hinges only"
+                    flip = ax[2] < 0
+                if flip:
+                    R = R @ Rx
+                carrier = len(bodies)
+                bodies.append(dict(name=b.get("name"), parent=parent, pos=p, quat=R_to_quat_wxyz(R), inertia=None,
+                                   joint=("free" if fj is not None else jn.get("name"))))
+                Rb, pb = (Rx if flip else np.eye(3)), np.zeros(3)   # the XML body frame seen from the (turned) body frame
+            ine = inertial_of(b)
+            if ine is not None:
+                ine = ine.transformed(Rb, pb)
+                cur = bodies[carrier]["inertia"]
+                bodies[carrier]["inertia"] = ine if cur is None else cur + ine
+            for g in b.findall("geom"):
+                if g.get("type", "sphere") != "mesh" or g.get("class") == "visualgeom" or int(g.get("contype", g_contype)) == 0:
+                    continue
+                Rg = Rb @ quat_wxyz_to_R(_floats(g.get("quat", "1 0 0 0")))
+                pg = Rb @ _floats(g.get("pos", "0 0 0")) + pb
+                geoms.append(dict(name=g.get("name"), body=carrier, R=Rg, p=pg, mesh=g.get("mesh")))
+            walk(b, carrier, Rb, pb)
+
+    walk(root.find("worldbody"), -1, np.eye(3), np.zeros(3))
+    for b in bodies:
+        assert b["inertia"] is not None and b["inertia"].mass > 0, f"body {b['name']} has no mass"
+    actuators = [p.get("joint") for p in root.find("actuator").findall("position")]
+
+    # hulls per geom, vertices in the BODY frame, k-d ordered chunks (as build_sim_model does per body)
+    hull_cache = {}
+    hull_v, hull_adr, edge_adr, edges, rb, chunk_adr, chunk_box, hull_center, hull_box = [], [0], [0], [], [], [0], [], [], []
+    for g in geoms:
+        if g["mesh"] not in hull_cache:
+            hull_cache[g["mesh"]] = convex_hull_graph(load_stl_vertices(mesh_dir / mesh_file[g["mesh"]]))
+        hv, eadr, e = hull_cache[g["mesh"]]
+        hv_body = hv @ g["R"].T + g["p"]
+        perm = kd_order(hv_body)
+        inv = np.empty_like(perm)
+        inv[perm] = np.arange(len(perm))
+        hv_body = hv_body[perm]
+        nb_lists = [sorted(int(inv[j]) for j in e[eadr[old]:eadr[old + 1]]) for old in perm]
+        eadr2 = np.concatenate([[0], np.cumsum([len(x) for x in nb_lists])]).astype(np.int32)
+        e2 = np.array([j for x in nb_lists for j in x], np.int32)
+        for c0 in range(0, len(hv_body), CHUNK):
+            blk = hv_body[c0:c0 + CHUNK]
+            lo, hi = blk.min(0), blk.max(0)
+            chunk_box.append(np.concatenate([0.5 * (lo + hi), 0.5 * (hi - lo)]))
+        chunk_adr.append(len(chunk_box))
+        c = 0.5 * (hv_body.min(0) + hv_body.max(0))
+        rb.append(np.concatenate([c, [np.linalg.norm(hv_body - c, axis=1).max()]]))
+        hull_center.append(hull_volume_centroid(hv_body))
+        hull_box.append(np.concatenate([c, 0.5 * (hv_body.max(0) - hv_body.min(0))]))
+        hull_v.append(hv_body)
+        edge_adr.extend((eadr2[1:] + len(edges)).tolist())
+        edges.extend(e2.tolist())
+        hull_adr.append(hull_adr[-1] + len(hv_body))
+    return dict(
+        bodies=bodies, geoms=geoms, excl=np.zeros((0, 2), np.int32), actuators=actuators,
+        frictionloss=frictionloss, armature=armature, damping=damping, kp=kp, dampratio=0.0,
+        ctrlrange=ctrlrange, forcerange=forcerange,
+        condim=max(g_condim, 3), friction=g_friction, solref=g_solref, margin=g_margin,
+        hull_v=np.concatenate(hull_v), hull_adr=np.array(hull_adr, np.int32),
+        edge_adr=np.array(edge_adr, np.int32), edges=np.array(edges, np.int32), rbound=np.array(rb),
+        chunk_adr=np.array(chunk_adr, np.int32), chunk_box=np.array(chunk_box),
+        hull_center=np.array(hull_center), hull_box=np.array(hull_box),
+    )
+
+
 if __name__ == "__main__":
     ref = Path(sys.argv[1] if len(sys.argv) > 1 else "/root/reference")
     out = Path(sys.argv[2] if len(sys.argv) > 2 else Path(__file__).parent / "assets" / "op3_v1.tsidb")
     ts, sim, c0, sec = compile_model(ref, out)
-    emit_topology_header(sec["mj_parent"], Path(__file__).parent / "csrc" / "tsidb_topology.hpp")
-    # the v0 robot: TSID side only (its MJCF needs sim features that are not built)
+    emit_topology_header(sec["mj_parent"], Path(__file__).parent / "csrc" / "tsidb_topology.hpp",
+                         ng=len(sec["mj_geom_body"]), npair=len(sec["mj_pairs"]))
+    # the v0 robot (legacy/op3_conf.py:53-62): robot/v0/robot.urdf + robot.srdf, robot/v0/robot.xml + meshes/*.stl
     v0 = ref / "robot" / "v0"
-    ts0, sec0 = compile_tsid_only(v0 / "robot.urdf", v0 / "robot.srdf",
-                                  ["leg_left_sole_joint_fixed", "leg_right_sole_joint_fixed"],
-                                  out.parent / "op3_v0.tsidb")
-    emit_topology_header(sec0["pin_parent"], Path(__file__).parent / "csrc" / "tsidb_topology_v0.hpp", has_sim=False)
-    print("v0 joints:", ts0["names"], "mass", ts0["inertia"][:, 0].sum())
+    ts0 = build_tsid_model(v0 / "robot.urdf", v0 / "robot.srdf", ["leg_left_sole_joint_fixed", "leg_right_sole_joint_fixed"])
+    sim0 = build_sim_model_mjcf(v0 / "robot.xml", v0 / "meshes")
+    _, _, _, sec0 = assemble_blob(ts0, sim0, out.parent / "op3_v0.tsidb")
+    emit_topology_header(sec0["mj_parent"], Path(__file__).parent / "csrc" / "tsidb_topology_v0.hpp",
+                         ng=len(sec0["mj_geom_body"]), condim=int(sec0["mj_contact"][8]), eulerdamp=bool(sec0["mj_damping"].any()),
+                         npair=len(sec0["mj_pairs"]))
+    print("v0 joints:", ts0["names"], "mass", ts0["inertia"][:, 0].sum(), "geoms", len(sec0["mj_geom_body"]), "pairs", len(sec0["mj_pairs"]))
     print("joints:", ts["names"])
     print("total mass (TSID):", ts["inertia"][:, 0].sum(), " (sim):", sum(b["inertia"].mass for b in sim["bodies"]))
     print("hull verts:", len(sim["hull_v"]), "edges:", len(sim["edges"]), "blob bytes:", out.stat().st_size)
