@@ -100,8 +100,9 @@ int tsidb_tick(tsidb_handle h, void *q, void *v, void *tau, void *dv, void *f, i
  * [N,26] (may be NULL) is used only with params[QUIRKS] = 0: the base velocity is then set together with
  * the base pose (the reference writes qpos[:7] only, which leaves the sim's base velocity to drift once
  * the TSID state moves).  qpos [N,27], qvel [N,26], qacc_ws [N,26] updated in place; qacc [N,26], ncon [N],
- * con_pairs [N,32] = (body << 16 | hull vertex), -1 padded; info [N,4] slots 2,3 = solver
- * iterations, failure bits (all may be NULL). */
+ * con_pairs [N,32] = (geom << 16 | hull vertex) for floor contacts, (geom2 << 16 | 0x8000 | geom1) for robot<->robot
+ * ones, -1 padded (geom = collision geom in the blob's order; the v1 robot has one per body, in body order);
+ * info [N,4] slots 2,3 = solver iterations, failure bits (all may be NULL). */
 int tsidb_sim(tsidb_handle h, const void *q_tsid, const void *v_tsid, void *qpos, void *qvel, void *qacc_ws,
               void *qacc, int32_t *ncon, int32_t *con_pairs, int32_t *info, void *stream);
 
@@ -145,7 +146,7 @@ int tsidb_rbd_terms(tsidb_handle h, const void *q, const void *v, void *M, void 
                     void *oMf, void *com, void *stream);
 
 /* dimensions of the robot this library was built for (one library per robot: libtsidb.so = the v1 robot of ctrl/conf.py:9-15,
- * libtsidb_v0.so = robot/v0, TSID side only): out6 = NJ, NQ, NV, NA, sim bodies, 1 if the sim stage is built.  The TSIDB_N*
+ * libtsidb_v0.so = robot/v0): out6 = NJ, NQ, NV, NA, sim bodies, 1 if the sim stage is built.  The TSIDB_N*
  * constants above are the v1 robot's. */
 int tsidb_dims(int *out6);
 

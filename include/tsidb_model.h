@@ -37,18 +37,28 @@
  *   mj_act_kv         f64 [20]      2 * dampratio * sqrt(kp * dof_M0)  (robot.xml:9, computed as MuJoCo's compiler does)
  *   mj_ctrl_qidx      i32 [20]      TSID q index feeding actuator i: main.py:11-44, derived by joint name
  *   mj_sim2tsid       i32 [20]      sim joint i -> TSID joint index
- *   mj_hull_adr       i32 [22]      first hull vertex of each body's collision hull
+ *   mj_damping        f64 [26]      joint damping per dof (robot/v0/robot.xml:3; all 0 for v1)
+ *   mj_act_range      f64 [20][4]   ctrlrange lo, hi, forcerange lo, hi per actuator (+-1e300 = unlimited; robot/v0/robot.xml:5)
+ *   mj_geom_body      i32 [NG]      body carrying collision geom g (v1: one geom per body, identity; v0: 52 geoms on 19 bodies);
+ *                                   the geom-indexed sections below hold the geom's hull in the frame of that body
+ *   mj_hull_adr       i32 [NG+1]    first hull vertex of each geom's collision hull
  *   mj_hull_vert      f64 [11335][3] convex-hull vertices, BODY frame, k-d order (runs of 64 = one chunk)
  *   mj_hull_eadr      i32 [11336]   neighbour-list start per vertex; mj_hull_edge i32 [...] neighbour ids
- *                                   local to the body's hull (edges of the triangulated hull)
- *   mj_chunk_adr      i32 [22]      first chunk of each body; mj_chunk_box f64 [188][6] centre, half extent
- *   mj_rbound         f64 [21][4]   bounding sphere (centre in the body frame, radius)
- *   mj_hull_center    f64 [21][3]   centre of mass of the solid hull, body frame (the geom centre MuJoCo's convex
+ *                                   local to the geom's hull (edges of the triangulated hull)
+ *   mj_chunk_adr      i32 [NG+1]    first chunk of each geom; mj_chunk_box f64 [188][6] centre, half extent
+ *   mj_rbound         f64 [NG][4]   bounding sphere (centre in the body frame, radius)
+ *   mj_hull_center    f64 [NG][3]   centre of mass of the solid hull, body frame (the geom centre MuJoCo's convex
  *                                   collision starts its portal search from)
- *   mj_hull_box       f64 [21][6]   body-frame bounding box of the hull: centre, half extents (mid phase)
- *   mj_pairs          i32 [170][2]  robot<->robot candidate body pairs (after excludes and parent-child filter)
+ *   mj_hull_box       f64 [NG][6]   body-frame bounding box of the hull: centre, half extents (mid phase)
+ *   mj_pairs          i32 [170][2]  robot<->robot candidate GEOM pairs (after excludes, parent-child and same-body filter;
+ *                                   v0: 1044)
  *   mj_opt            f64 [7]       timestep, gravity z, tolerance, iterations, ls_iterations, ls_tolerance, impratio
- *   mj_contact        f64 [8]       friction mu, solref (2), solimp (5)  - MuJoCo defaults (no geom contact attrs)
+ *   mj_contact        f64 [12]      friction mu, solref (2), solimp (5), condim, torsional friction, margin, spare
+ *                                   (v1: MuJoCo defaults, condim 3; v0: robot/v0/robot.xml:4)
+ *
+ *  model_dims         i32 [9]       NJ, NQ, NV, NA, sim bodies, 1 if sim sections are present, NG, condim, 1 if any joint is
+ *                                   damped - checked against the library build at tsidb_create (one build per robot; the
+ *                                   sizes quoted above are the v1 robot's, the v0 blob has 19 / 25 / 24 / 18 / 19 / 52)
  */
 #ifndef TSIDB_MODEL_H
 #define TSIDB_MODEL_H
