@@ -59,6 +59,9 @@ def parse():
     ap.add_argument("--envs-per-gpu", type=int, default=None, help="same as --weak --envs N")
     ap.add_argument("--dtype", choices=["f64", "f32"], default="f64")
     ap.add_argument("--workload", choices=["walk", "stand"], default="walk")
+    ap.add_argument("--robot", choices=["v1", "v0"], default="v1",
+                    help="v0: the reference's second robot (robot/v0, libtsidb_v0.so; SURVEY 8f-4) - standing workload only "
+                         "(the reference has no walking configuration for it)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline budget; 0 disables it")
     ap.add_argument("--cpu-sample", type=int, default=256)
     ap.add_argument("--randomize", action="store_true",
@@ -111,7 +114,7 @@ def cpu_baseline(wc, sched, t_now, seconds, sample):
     from oracle.oracle import Oracle, WalkTables, new_state
     n = min(sample, wc.num_envs)
     orc = Oracle(wc.model.raw)
-    st = new_state(n)
+    st = new_state(n, (wc.NQ, wc.NV, wc.NA))
     for k in ("q", "v", "qpos", "qvel", "com_ref", "posture_ref", "foot_ref", "contact_ref", "cop_frames", "contact_active"):
         st[k][...] = getattr(wc, k)[:n].double().cpu().numpy().reshape(st[k].shape) if k != "contact_active" \
             else wc.contact_active[:n].cpu().numpy()
@@ -160,7 +163,14 @@ def run_workload(a, dev, rank, world, n, with_gather=True):
     from tsid_control_amd.walk_planner import WalkSchedule, op3_walking_conf, op3_walking_posture
     import torch.distributed as dist
 
-    conf = RobotConfig()
+    robot = getattr(a, "robot", "v1")
+    if robot == "v0":
+        from tsid_control_amd import op3_v0_conf
+        if a.workload != "stand":
+            raise SystemExit("--robot v0 runs the standing workload only: add --workload stand")
+        conf = op3_v0_conf()
+    else:
+        conf = RobotConfig()
     conf.dtype = a.dtype
     conf.self_collision = bool(a.self_collision)
     if a.workload == "walk":
@@ -185,8 +195,8 @@ def run_workload(a, dev, rank, world, n, with_gather=True):
             g = torch.Generator().manual_seed(7 + rank)
             sched.set_phase_offsets(torch.rand(n, generator=g, dtype=torch.float64) * a.dephase)
     else:  # config 2: perturbed standing
-        wc.q[:, 7:] += (torch.rand(n, 20, dtype=wc.dtype, device=dev) - 0.5) * 0.1
-        wc.v[:] = torch.randn(n, 26, dtype=wc.dtype, device=dev) * 0.05
+        wc.q[:, 7:] += (torch.rand(n, wc.NA, dtype=wc.dtype, device=dev) - 0.5) * 0.1
+        wc.v[:] = torch.randn(n, wc.NV, dtype=wc.dtype, device=dev) * 0.05
     # the gathered row per env: obs[65] + reward + done (SURVEY.md 8e "obs (+reward, done)")
     gather = ObsGather(n, wc.gather_width, world, wc.dtype, dev) if with_gather else None
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] if k % a.event_every == 0 else None
@@ -328,6 +338,9 @@ def workload_name(a, n):
         if a.tau_max_scaling is not None:
             s += f"; tau_max_scaling {a.tau_max_scaling}"
         return s
+    if getattr(a, "robot", "v1") == "v0":
+        return (f"cfg2 on the v0 robot (robot/v0: 18 actuated joints, 52 collision meshes, condim 4, joint damping): {n} "
+                f"perturbed stand/balance per GPU")
     return f"cfg2: {n} perturbed stand/balance per GPU"
 
 
@@ -394,7 +407,11 @@ def main():
         er, ewc, _, _ = run_workload(ea, dev, rank, world, n, with_gather=False)
         tick_ms, sim_ms = er["tick_ms"], er["sim_ms"]
         del ewc
-    dom, dom_ms, dom_words = ("k_tick", tick_ms, TICK_WORDS) if tick_ms >= sim_ms else ("k_sim", sim_ms, SIM_WORDS)
+    # DESIGN.md section 4 "Algorithmic bytes", with the robot's dimensions (v1: 347 and 185 words)
+    tick_words = (wc.NQ + wc.NV + 9 + wc.NA + 48 + 24 + 2) + (wc.NQ + wc.NV + wc.NA + wc.NV + 24 + 1 + wc.NOBS + 2)
+    sim_words = (wc.NQ + wc.NQ + 2 * wc.NV) + (wc.NQ + 2 * wc.NV)
+    assert args.robot != "v1" or (tick_words, sim_words) == (TICK_WORDS, SIM_WORDS)
+    dom, dom_ms, dom_words = ("k_tick", tick_ms, tick_words) if tick_ms >= sim_ms else ("k_sim", sim_ms, sim_words)
     if args.randomize and dom == "k_sim":
         dom_words += 8 + 20  # env_params row + terrain table row
     alg_bytes = n * dom_words * wsz

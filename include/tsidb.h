@@ -9,7 +9,8 @@
  * as void*).  Return 0 = OK, non-zero = library-level failure (message via tsidb_last_error);
  * a per-env QP failure is data in status[e] (tsid HQPStatus codes: 0 optimal, 1 infeasible,
  * 2 unbounded, 3 max-iter, 4 error), never a call failure - mirroring main.py:122-124 without
- * aborting the batch.  A handle is not thread-safe; one handle per GPU.
+ * aborting the batch: that env's tau, dv and f are 0 for the tick, its TSID state is left as it was, done = 1.
+ * A handle is not thread-safe; one handle per GPU.
  */
 #ifndef TSIDB_H
 #define TSIDB_H

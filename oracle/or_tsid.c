@@ -539,6 +539,8 @@ int or_tsid_tick_cop(const OrModel *m, const double *params, double *q, double *
   or_tsid_assemble_cop(m, params, &t, q, v, com_ref, posture_ref, foot_ref, contact_ref, contact_active, cop_ref, &qp);
   int status = or_qp_solve(&qp, (int)params[P_MAX_ITER], &sol);
   if (iters) *iters = sol.iter;
+  /* a failed QP (the reference stops its loop there, main.py:122-124, before it reads the solution): dv = f = tau = 0 */
+  if (status != 0) memset(sol.x, 0, sizeof sol.x);
   memset(f, 0, 24 * sizeof(double));
   for (int i = 0; i < OR_NV; i++) dv[i] = sol.x[i];
   for (int s = 0; s < 2; s++)
@@ -562,7 +564,7 @@ int or_tsid_tick_cop(const OrModel *m, const double *params, double *q, double *
       const double sat = (v[6 + r] + params[P_DT] * dv[6 + r]) * 20.0;
       a += params[P_FRICTION_COMP] * (sat > 1 ? 1.0 : (sat < -1 ? -1.0 : sat));
     }
-    tau[r] = a;
+    tau[r] = status == 0 ? a : 0.0;
   }
   /* observations use the data of this tick's computeProblemData (before integration), as
    * main.py:132-142 reads formulation.data() after integrate_dv without recomputing */

@@ -1108,13 +1108,16 @@ __device__ __forceinline__ void tsid_tick_env(const DevModel<T> &m, TickLds<T> &
   int status = qp_status, iters = qp_iters;
 
   TSIDB_STAMP(8);
-  // ---- decode: dv, f, tau = M_a dv + h_a - J_a^T f
-  if (lane < NV) dv[lane] = L.x[lane];
+  // ---- decode: dv, f, tau = M_a dv + h_a - J_a^T f.  A failed QP (the reference stops its loop there, main.py:122-124,
+  //      before it reads the solution) leaves dv = f = tau = 0: nothing of the solver's last iterate is handed on, and in
+  //      the closed loop the env's motors go limp instead of being driven by it
+  const bool solved = status == 0;
+  if (lane < NV) dv[lane] = solved ? L.x[lane] : T(0);
   if (lane < 24) {
     const int fo = lane / 12, e = lane % 12;
     T val = 0;
     for (int s = 0; s < c.nslot; s++)
-      if (c.slot_foot[s] == fo) val = L.x[NV + 12 * s + e];
+      if (solved && c.slot_foot[s] == fo) val = L.x[NV + 12 * s + e];
     fout[lane] = val;
     L.as.s[lane] = val; // staged for the CoP
   }
@@ -1126,6 +1129,7 @@ __device__ __forceinline__ void tsid_tick_env(const DevModel<T> &m, TickLds<T> &
       const T vn = L.vs[6 + lane] + m.params[P_DT] * L.x[6 + lane], sat = vn * T(20);
       t += m.params[P_FRICTION_COMP] * (sat > 1 ? T(1) : (sat < -1 ? T(-1) : sat));
     }
+    t = solved ? t : T(0);
     tau[lane] = t;
     tau2 = t * t;
   }
