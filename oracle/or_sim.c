@@ -191,12 +191,13 @@ int or_sim_step_ext(const OrModel *m, double *qpos, double *qvel, const double *
   static __thread OrSimInfo local;
   if (!info) info = &local;
   memset(info, 0, sizeof *info);
-  { /* non-finite state / targets: the step is skipped */
-    double chk = 0;
-    for (int i = 0; i < OR_NQ; i++) chk += fabs(qpos[i]);
-    for (int i = 0; i < NV; i++) chk += fabs(qvel[i]) + fabs(qacc_ws[i]);
+  { /* non-finite state / targets, or a state that has diverged (sum |qpos| + |qvel| > 1e6: the reference's own
+     * teleported sim gets there): the step is skipped */
+    double chk = 0, big = 0;
+    for (int i = 0; i < OR_NQ; i++) big += fabs(qpos[i]);
+    for (int i = 0; i < NV; i++) { big += fabs(qvel[i]); chk += fabs(qacc_ws[i]); }
     for (int i = 0; i < OR_NA; i++) chk += fabs(ctrl[i]) + (motor_tau ? fabs(motor_tau[i]) : 0.0);
-    if (!(chk <= 1e300)) return 4;
+    if (!(chk <= 1e300) || !(big <= 1e6)) return 4;
   }
 
   /* ---------------- kinematics */

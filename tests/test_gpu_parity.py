@@ -552,6 +552,34 @@ def test_non_finite_inputs_are_contained(oracle):
     assert diff(wc.qpos[good], st["qpos"][good]) < 1e-9
 
 
+def test_diverged_sim_state_is_contained(oracle):
+    """A finite but absurd sim state (the reference's own standing loop drives its teleported sim to 1e150 within 700
+    ticks; products of such values overflow to inf / NaN inside the step, and a NaN placement used to index the hull
+    arrays out of bounds - a GPU memory fault): the env is skipped and flagged (info[3] bit 4) like a non-finite one,
+    on the device as in the oracle; states just inside the bound are stepped and agree."""
+    n = 8
+    wc = make(n)
+    wc.qpos[:, 3:7] = torch.tensor([1.0, 0, 0, 0], dtype=wc.dtype, device=wc.device)
+    wc.qvel[1, 9] = 1e150
+    wc.qvel[2, 2] = -2e6
+    wc.qpos[3, 0] = 1e200
+    wc.qvel[4, 2] = -9e5          # inside the bound
+    wc.qvel[5, 12] = 3e4          # a joint spinning absurdly fast, inside the bound
+    qpos, qvel, ws = (x.cpu().numpy().copy() for x in (wc.qpos, wc.qvel, wc.qacc_warmstart))
+    before = (qpos.copy(), qvel.copy())
+    wc.sim_step(teleport=False)
+    info = wc.info.cpu().numpy()
+    for e in range(n):
+        r = oracle.sim_step(qpos[e], qvel[e], np.zeros(20), ws[e])
+        assert (r["rc"] == 4) == (e in (1, 2, 3)) == bool(info[e, 3] & 4), e
+    for e in (1, 2, 3):
+        assert np.array_equal(wc.qpos[e].cpu().numpy(), before[0][e]) and np.array_equal(wc.qvel[e].cpu().numpy(), before[1][e])
+        assert int(wc.ncon[e]) == 0
+    ok = [0, 4, 5, 6, 7]
+    assert bool(torch.isfinite(wc.qpos[ok]).all())
+    assert diff(wc.qpos[ok], qpos[ok]) < 1e-6 * max(1.0, float(np.abs(qpos[ok]).max())) and diff(wc.qvel[ok], qvel[ok]) < 1e-6 * 9e5
+
+
 def test_fallen_robot_hits_the_contact_cap(oracle):
     """A robot lying on the floor: more hull vertices touch than the 32-contact cap; the sim keeps the
     first 32 in body order like the oracle (bit-exact pairs) and stays finite."""

@@ -117,3 +117,20 @@ def test_non_finite_state_skips_the_step(oracle):
     before = qpos.copy()
     r = oracle.sim_step(qpos, qvel, np.zeros(20), ws)
     assert r["rc"] == 4 and np.array_equal(before, qpos, equal_nan=True) and r["ncon"] == 0
+
+
+def test_diverged_state_skips_the_step(oracle):
+    """a finite but absurd state (the reference's teleported sim reaches 1e150 within 700 ticks of the standing loop: its
+    base velocity accumulates until the contact forces explode) is treated like a non-finite one: sum |qpos| + |qvel| > 1e6"""
+    for bad in (("qvel", 8, 2e6), ("qpos", 0, -3e6), ("qvel", 20, 1e150)):
+        qpos = np.zeros(NQ); qpos[2] = 0.5; qpos[3] = 1.0
+        qvel, ws = np.zeros(NV), np.zeros(NV)
+        (qpos if bad[0] == "qpos" else qvel)[bad[1]] = bad[2]
+        b4 = (qpos.copy(), qvel.copy())
+        r = oracle.sim_step(qpos, qvel, np.zeros(20), ws)
+        assert r["rc"] == 4 and np.array_equal(b4[0], qpos) and np.array_equal(b4[1], qvel)
+    qpos = np.zeros(NQ); qpos[2] = 0.5; qpos[3] = 1.0
+    qvel, ws = np.zeros(NV), np.zeros(NV)
+    qvel[2] = -9e5                                            # fast, but inside the bound: stepped
+    r = oracle.sim_step(qpos, qvel, np.zeros(20), ws)
+    assert r["rc"] == 0 and qpos[2] < -1000

@@ -80,12 +80,15 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2))) void 
   if (e >= n) return;
   const size_t E = (size_t)e;
   {
-    // non-finite sim state / targets: skip the step, failure bit 4 in info[3]
-    T chk = 0;
-    if (lane < NQ) chk += fabs(qpos[E * NQ + lane]) + (q_tsid ? fabs(q_tsid[E * NQ + lane]) : T(0));
-    if (lane < NV) chk += fabs(qvel[E * NV + lane]) + fabs(qacc_ws[E * NV + lane]) + (v_tsid ? fabs(v_tsid[E * NV + lane]) : T(0));
+    // non-finite sim state / targets, or a sim state that has diverged (sum of |qpos| + |qvel| beyond SIM_STATE_BOUND:
+    // the reference's own loop gets there, its teleported sim accumulates velocity until the contact forces explode -
+    // and products of such values overflow to inf / NaN inside the step): skip the step, failure bit 4 in info[3]
+    T chk = 0, big = 0;
+    if (lane < NQ) { big += fabs(qpos[E * NQ + lane]); chk += q_tsid ? fabs(q_tsid[E * NQ + lane]) : T(0); }
+    if (lane < NV) { big += fabs(qvel[E * NV + lane]); chk += fabs(qacc_ws[E * NV + lane]) + (v_tsid ? fabs(v_tsid[E * NV + lane]) : T(0)); }
     if (lane < NA && motor_tau) chk += fabs(motor_tau[E * NA + lane]);
-    if (__ballot(!(chk <= Eps<T>::inf))) {
+    big = wave_sum(big);
+    if (__ballot(!(chk <= Eps<T>::inf)) || !(big <= T(SIM_STATE_BOUND))) {
       if (lane == 0) {
         if (info) { info[E * 4 + 2] = 0; info[E * 4 + 3] = 4; }
         if (ncon) ncon[e] = 0;

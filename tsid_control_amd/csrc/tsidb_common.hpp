@@ -192,6 +192,8 @@ __device__ __forceinline__ void sincos_t(double x, double &s, double &c) {
   c = ((q + 1) & 2) ? -c0 : c0;
 }
 
+// a sim state with sum |qpos| + sum |qvel| beyond this (m, rad, m/s, rad/s) has diverged: the step is skipped and flagged
+constexpr double SIM_STATE_BOUND = 1e6;
 template <typename T> struct Eps;
 template <> struct Eps<double> { static constexpr double v = 2.220446049250313e-16; static constexpr double inf = 1e300; };
 template <> struct Eps<float> { static constexpr float v = 1.1920929e-07f; static constexpr float inf = 1e30f; };

@@ -277,7 +277,8 @@ __device__ __forceinline__ int hull_argmin(const DevModel<T> &m, int lane, int b
     if (i < v1 && vert_val(i) <= zt) cand = i;
     best = wave_min_int(cand);
   }
-  return best;
+  // non-finite values (a NaN placement) match nothing: hand back a valid index, the callers index global memory with it
+  return best == 0x7fffffff ? v0 : best;
 }
 
 template <typename T> __device__ __forceinline__ bool normalize3(T *a) {
@@ -864,7 +865,7 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
     const int best = has_terr ? hull_argmin<T, true>(m, lane, g, r6, r7, r8, pz, tie_tol, L.terr, Rb, L.p[b][0] + Ow[0],
                                                      L.p[b][1] + Ow[1], hmax_all, zmin)
                               : hull_argmin<T, false>(m, lane, g, r6, r7, r8, pz, tie_tol, nullptr, nullptr, T(0), T(0), T(0), zmin);
-    if (zmin > margin) continue;
+    if (!(zmin <= margin)) continue; // (also when zmin is NaN)
     // the support vertex, then its hull-graph neighbours within the margin
     const int e0 = m.hull_eadr[best];
     int nnb = m.hull_eadr[best + 1] - e0;
