@@ -52,6 +52,9 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2))) void 
       return;
     }
   }
+#ifdef TSIDB_ONLY_NS // (diagnostic builds: one body, to read its resource usage alone)
+  if (ns != TSIDB_ONLY_NS) return;
+#endif
   if (ns == 2) {
     tsid_tick_env<T, 2, COP>(*mp, L, lane, q + E * NQ, v + E * NV, com_ref + E * 9, posture_ref + E * NA, foot_ref + E * 48,
                          contact_ref + E * 24, cact + E * 2, cop_frames ? cop_frames + E * 24 : nullptr, tau + E * NA,

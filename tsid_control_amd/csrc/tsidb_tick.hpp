@@ -340,6 +340,8 @@ __device__ __forceinline__ void se3_rhs(const TickLds<T> &L, int f, const T *ref
   }
 }
 
+#define ORDER_PIN2(x, y) asm volatile("" : "+v"(x), "+v"(y))
+
 // --------------------------------------------------------------------------- QP pieces
 __device__ __forceinline__ int rcol(int c) { return c * (c + 1) / 2; } // packed upper-triangular column start
 
@@ -586,11 +588,12 @@ __device__ __forceinline__ int qp_active_regs(const DevModel<T> &m, TickLds<T> &
             const T nrm = sqrt(alpha * alpha + sigma);
             const T v0 = alpha + (alpha >= 0 ? nrm : -nrm);
             const T beta = T(2) / (v0 * v0 + sigma);
-            const T vl = lane == cstar ? v0 : dfree;
+            T vl = lane == cstar ? v0 : dfree;
             T w = 0;
 #pragma unroll
             for (int j = PP; j < NN; j++) w += jr[j] * rdlane(vl, j);
             w *= beta;
+            asm volatile("" : "+v"(vl)); // broadcast again rather than keep NN - PP SGPR pairs (spilled to VGPR lanes) alive
 #pragma unroll
             for (int j = PP; j < NN; j++) jr[j] -= w * rdlane(vl, j);
             dnew = alpha >= 0 ? -nrm : nrm;
@@ -727,52 +730,86 @@ __device__ __forceinline__ int qp_active_regs(const DevModel<T> &m, TickLds<T> &
 // register-resident rows/columns and every unrolled loop carry no padding for absent contacts.
 template <typename T, int NS, bool COP>
 __device__ __forceinline__ void tick_qp(const DevModel<T> &m, TickLds<T> &L, QpCtx<T> &c, int lane, const T (&a)[NV],
-                                        const T (&rd)[NV], T gi, T c1, bool spd, const T *cop_ref, int &qp_status, int &qp_iters) {
+                                        T rdv, T gi, T c1, bool spd, const T *cop_ref, int &qp_status, int &qp_iters) {
+  // ORDER_PIN2(x, y): an empty volatile asm that "modifies" x and y.  The unrolled loops below use every broadcast value
+  // (v_readlane -> an SGPR pair) twice, in two FMA chains; the compiler likes to run one chain for the whole loop and
+  // then the other, keeping all the loop's broadcast values alive in between - ~100 SGPRs it does not have, so it spills
+  // each to a VGPR lane (v_writelane + wait states) and reloads it (v_readlane): 3 800 spill sites in this kernel, whose
+  // spill VGPRs in turn pushed the vector registers over budget.  Volatile asms keep their order, so pinning both
+  // accumulators after each step keeps the two uses adjacent.  Costs no instruction.
   // ---- three forward substitutions with L share its broadcast entries:
   //   y  = L^-1 (-g)                      (uniform, lane i contributes y_i)
   //   xr = L^-1 e_lane                    (column `lane` of L^-1 = row `lane` of J0 = L^-T)
   //   bc = L^-1 CE[lane][0:26]^T          (column `lane` of B = J0^T CE^T, lanes < p)
   constexpr int NN = NV + 12 * NS, PP = 6 + 6 * NS; // variables / equality constraints of this contact configuration
   const int p = PP, n = NN;
-  T bc[NN], jr[NN];
+  // B = J^T CE^T (NN x PP) is held by COLUMN, each column split over G lanes: lane c + PP g keeps rows
+  // [g GS, (g + 1) GS) of column c in bs[0..GS).  (One whole column per lane - the first version - costs NN doubles in
+  // every lane for PP useful lanes: with J's row of NN doubles beside it the double-support body spilled ~130 VGPRs.)
+  // (Measured and dropped, round 2: with <= 16 equalities the columns fit one 16-lane DPP row; every row of the wavefront
+  //  keeping a full copy, a reflector entry reaches all lanes with one v_mov_b64_dpp row_newbcast instead of a
+  //  v_readlane pair - but a full column per lane is 76 VGPRs again, the single-support body then spills 104, and
+  //  k_tick went from 0.154 to 0.174 ms on the walking workload.)
+  constexpr int G = 3, GS = (NN + G - 1) / G;
+  static_assert(G * PP <= WAVE, "the column groups of B must fit the wavefront");
+  const int grp = lane / PP, col = lane - grp * PP;
+  const bool bl = lane < G * PP; // this lane holds a part of column `col`
+  T jr[NN], bs[GS];
+  int ln = lane; // (re-read per phase: see tsid_tick_env)
+  asm volatile("" : "+v"(ln));
   {
-    T acc = -gi;
-    T yv = 0;
-    // CE row `lane`: base dynamics rows come from Dyn, contact motion rows from the frame Jacobians
-    const bool isbase = lane < 6;
-    const int crow = lane < 6 ? lane : (lane < p ? 6 * c.slot_foot[(lane - 6) / 6] + (lane - 6) % 6 : 0);
-#pragma unroll
-    for (int i = 0; i < NV; i++) {
-      // two partial sums per substitution: four independent FMA chains instead of two
-      T xs = lane == i ? T(1) : T(0), xs1 = 0;
-      T bs = lane < p ? (isbase ? L.Dyn[crow * LDD + i] : L.k.Jf[crow * LDF + i]) : T(0), bs1 = 0;
-#pragma unroll
-      for (int k = 0; k < i; k++) {
-        const T lik = rdlane(a[k], i);
-        if (k & 1) { xs1 -= lik * jr[k]; bs1 -= lik * bc[k]; }
-        else { xs -= lik * jr[k]; bs -= lik * bc[k]; }
-      }
-      jr[i] = (xs + xs1) * rd[i];
-      bc[i] = (bs + bs1) * rd[i];
-      const T yi = rdlane(acc, i) * rd[i];
-      if (lane == i) yv = yi;
-      acc -= a[i] * yi;
-    }
-    // x0 = L^-T y ; c_k = ce0_k + B[:,k] . y ; trace(J0)
     T x0 = 0, c2 = 0, ck = 0;
+    {
+      T bc[NV]; // rows 0..NV-1 of the column, computed alike by the G lanes that share it
+      T acc = -gi;
+      T yv = 0;
+      // CE row `col`: base dynamics rows come from Dyn, contact motion rows from the frame Jacobians
+      const bool isbase = col < 6;
+      const int crow = col < 6 ? col : 6 * c.slot_foot[(col - 6) / 6] + (col - 6) % 6;
 #pragma unroll
-    for (int i = 0; i < NV; i++) {
-      const T yi = rdlane(yv, i);
-      x0 += jr[i] * yi;
-      ck += bc[i] * yi;
-      c2 += rdlane(jr[i], i);
+      for (int i = 0; i < NV; i++) {
+        const T rdi = rdlane(rdv, i); // 1 / L[i][i] (lane i keeps it: 26 wave-uniform doubles held across these loops
+                                      // are 52 SGPRs the kernel does not have)
+        // two partial sums per substitution: four independent FMA chains instead of two
+        T xs = ln == i ? T(1) : T(0), xs1 = 0;
+        T bsum = bl ? (isbase ? L.Dyn[crow * LDD + i] : L.k.Jf[crow * LDF + i]) : T(0), bsum1 = 0;
+#pragma unroll
+        for (int k = 0; k < i; k++) {
+          const T lik = rdlane(a[k], i);
+          // ORDER_PIN: both uses of a broadcast value stay together (see tick_qp's header)
+          if (k & 1) { xs1 -= lik * jr[k]; bsum1 -= lik * bc[k]; ORDER_PIN2(xs1, bsum1); }
+          else { xs -= lik * jr[k]; bsum -= lik * bc[k]; ORDER_PIN2(xs, bsum); }
+        }
+        jr[i] = (xs + xs1) * rdi;
+        bc[i] = (bsum + bsum1) * rdi;
+        const T yi = rdlane(acc, i) * rdi;
+        if (ln == i) yv = yi;
+        acc -= a[i] * yi;
+      }
+      // x0 = L^-T y ; c_k = ce0_k + B[:,k] . y ; trace(J0)
+#pragma unroll
+      for (int i = 0; i < NV; i++) {
+        const T yi = rdlane(yv, i);
+        x0 += jr[i] * yi;
+        ck += bc[i] * yi;
+        if (ln == i) c2 = jr[i];
+      }
+      c2 = wave_sum(c2) + T(c.nslot) * m.Jf0_trace;
+      if (bl) {
+        if (col < 6) ck += L.h[col];
+        else ck -= L.k.arhs[c.slot_foot[(col - 6) / 6]][(col - 6) % 6];
+      }
+      // rows of the dv block go to their group's lane
+#pragma unroll
+      for (int j = 0; j < GS; j++) {
+        const T v0 = j < NV ? bc[j] : T(0), v1 = GS + j < NV ? bc[GS + j < NV ? GS + j : 0] : T(0),
+                v2 = 2 * GS + j < NV ? bc[2 * GS + j < NV ? 2 * GS + j : 0] : T(0);
+        bs[j] = grp == 0 ? v0 : (grp == 1 ? v1 : v2);
+      }
     }
-    c2 += T(c.nslot) * m.Jf0_trace;
-    if (lane < 6) ck += L.h[lane];
-    else if (lane < p) ck -= L.k.arhs[c.slot_foot[(lane - 6) / 6]][(lane - 6) % 6];
     // force rows: J0 row of the constant block; B rows 26.. = L_f^-1 (-Jc)^T for the base-dynamics columns
 #pragma unroll
-    for (int j = NV; j < NN; j++) { jr[j] = 0; bc[j] = 0; }
+    for (int j = NV; j < NN; j++) jr[j] = 0;
     if (lane >= NV && lane < n) {
 #pragma unroll
       for (int i = 0; i < NV; i++) jr[i] = 0;
@@ -787,131 +824,176 @@ __device__ __forceinline__ void tick_qp(const DevModel<T> &m, TickLds<T> &L, QpC
 #pragma unroll
       for (int i = 0; i < NV; i++) jr[i] = 0;
     }
-    if (lane < 6) {
-#pragma unroll
-      for (int s2 = 0; s2 < NS; s2++) {
-        T ce[12];
-#pragma unroll
-        for (int b = 0; b < 12; b++) ce[b] = L.Dyn[lane * LDD + NV + 12 * s2 + b];
-#pragma unroll
-        for (int e = 0; e < 12; e++) {
-          T sacc = 0;
-#pragma unroll
-          for (int b = 0; b <= e; b++) sacc += m.Jf0[b][e] * ce[b];
-          bc[NV + 12 * s2 + e] = sacc;
-        }
+    if constexpr (NS > 0) {
+      // rows NV.. of B (non-zero for the base-dynamics columns only): fc[col][e] = sum_{b <= e} Jf0[b][e] Dyn[col][NV + b],
+      // 6 x 12 NS dot products spread over the wavefront and handed over through LDS (the Jacobian scratch is dead now;
+      // six lanes doing it alone read the 78 constants of Jf0 as wave-uniform scalars: 156 SGPRs at once)
+      static_assert(6 * 12 * NS <= 160, "force rows are staged in the active-set row buffer");
+      T *fcl = L.as.s;
+      __syncthreads();
+      for (int idx = lane; idx < 6 * 12 * NS; idx += WAVE) {
+        const int cl = idx / (12 * NS), rem = idx % (12 * NS), s2 = rem / 12, e = rem % 12;
+        T sacc = 0;
+        for (int b = 0; b <= e; b++) sacc += m.Jf0[b][e] * L.Dyn[cl * LDD + NV + 12 * s2 + b];
+        fcl[idx] = sacc;
       }
-    }
-    if constexpr (NS > 0 && COP) {
-      const T w_cop = m.params[P_W_COP];
-      if (w_cop != 0 && cop_ref) {
-        // CoP force task (legacy/biped.py:79-80, tsid TaskCopEquality): cost w |t x sum_i (x_i - p_ref) x f_i|^2 over the
-        // two tangents t of the contact normal, x_i the world position of contact point i, f_i its force - the
-        // tangential moment of the contact forces about the reference CoP.  Its Hessian w A^T A (A: 2 x 12 NS) is a
-        // rank-2 term on top of the constant force-regularisation block L0 L0^T, so the factor J with J J^T = H_f^-1
-        // is J0 (I - b1 a1 a1^T)(I - b2 b b^T) with a_k = rows of A J0: two rank-1 corrections of the constant rows.
-        const int col = lane - NV; // force variable of this lane
-        const bool isf = lane >= NV && lane < n;
-        const T tiny = sizeof(T) == 8 ? T(1e-30) : T(1e-20);
-        T A0 = 0, A1 = 0;
-        if (isf) {
-          const int sl = col / 12, pt = (col % 12) / 3, j = col % 3, f = c.slot_foot[sl];
-          const T *R = L.oMf[f], *pp = L.oMf[f] + 9;
-          const T *r = &m.params[P_CPOINTS + 3 * pt];
-          T d[3], x1[3], x2[3];
+      __syncthreads();
+      if constexpr (COP) {
+        const T w_cop = m.params[P_W_COP];
+        if (w_cop != 0 && cop_ref) {
+          // CoP force task (legacy/biped.py:79-80, tsid TaskCopEquality): cost w |t x sum_i (x_i - p_ref) x f_i|^2 over the
+          // two tangents t of the contact normal, x_i the world position of contact point i, f_i its force - the
+          // tangential moment of the contact forces about the reference CoP.  Its Hessian w A^T A (A: 2 x 12 NS) is a
+          // rank-2 term on top of the constant force-regularisation block L0 L0^T, so the factor J with J J^T = H_f^-1
+          // is J0 (I - b1 a1 a1^T)(I - b2 b b^T) with a_k = rows of A J0: two rank-1 corrections of the constant rows.
+          const int fcol = lane - NV; // force variable of this lane
+          const bool isf = lane >= NV && lane < n;
+          const T tiny = sizeof(T) == 8 ? T(1e-30) : T(1e-20);
+          T A0 = 0, A1 = 0;
+          if (isf) {
+            const int sl = fcol / 12, pt = (fcol % 12) / 3, j = fcol % 3, f = c.slot_foot[sl];
+            const T *R = L.oMf[f], *pp = L.oMf[f] + 9;
+            const T *r = &m.params[P_CPOINTS + 3 * pt];
+            T d[3], x1[3], x2[3];
 #pragma unroll
-          for (int i = 0; i < 3; i++) d[i] = pp[i] + R[3 * i] * r[0] + R[3 * i + 1] * r[1] + R[3 * i + 2] * r[2] - cop_ref[i];
-          cross3(m.cop_t[0], d, x1);
-          cross3(m.cop_t[1], d, x2);
-          A0 = R[j] * x1[0] + R[3 + j] * x1[1] + R[6 + j] * x1[2]; // component j of R^T (t x d)
-          A1 = R[j] * x2[0] + R[3 + j] * x2[1] + R[6 + j] * x2[2];
-        }
-        __syncthreads();
-        if (isf) { L.x[col] = A0; L.x[24 + col] = A1; }
-        __syncthreads();
-        T t0 = 0, t1 = 0; // this lane's column of A J0 (J0 upper triangular within each foot's block)
-        if (isf) {
-          const int sl = col / 12, cb = col % 12;
-          for (int a2 = 0; a2 <= cb; a2++) {
-            const T jf = m.Jf0[a2][cb];
-            t0 += L.x[12 * sl + a2] * jf;
-            t1 += L.x[24 + 12 * sl + a2] * jf;
+            for (int i = 0; i < 3; i++) d[i] = pp[i] + R[3 * i] * r[0] + R[3 * i + 1] * r[1] + R[3 * i + 2] * r[2] - cop_ref[i];
+            cross3(m.cop_t[0], d, x1);
+            cross3(m.cop_t[1], d, x2);
+            A0 = R[j] * x1[0] + R[3 + j] * x1[1] + R[6 + j] * x1[2]; // component j of R^T (t x d)
+            A1 = R[j] * x2[0] + R[3 + j] * x2[1] + R[6 + j] * x2[2];
           }
+          __syncthreads();
+          if (isf) { L.x[fcol] = A0; L.x[24 + fcol] = A1; }
+          __syncthreads();
+          T t0 = 0, t1 = 0; // this lane's column of A J0 (J0 upper triangular within each foot's block)
+          if (isf) {
+            const int sl = fcol / 12, cb = fcol % 12;
+            for (int a2 = 0; a2 <= cb; a2++) {
+              const T jf = m.Jf0[a2][cb];
+              t0 += L.x[12 * sl + a2] * jf;
+              t1 += L.x[24 + 12 * sl + a2] * jf;
+            }
+          }
+          const T al1 = wave_sum(t0 * t0), a12 = wave_sum(t0 * t1);
+          const T be1 = al1 > tiny ? (1 - T(1) / sqrt(1 + w_cop * al1)) / al1 : T(0);
+          const T bq = t1 - be1 * a12 * t0;
+          const T al2 = wave_sum(bq * bq);
+          const T be2 = al2 > tiny ? (1 - T(1) / sqrt(1 + w_cop * al2)) / al2 : T(0);
+          __syncthreads();
+          if (isf) { L.x[fcol] = t0; L.x[24 + fcol] = bq; }
+          __syncthreads();
+          if (isf) { // row of J: j0 (I - b1 a1 a1^T)(I - b2 b b^T)
+            T s1 = 0, s2 = 0;
+#pragma unroll
+            for (int cc = 0; cc < 12 * NS; cc++) s1 += jr[NV + cc] * L.x[cc];
+#pragma unroll
+            for (int cc = 0; cc < 12 * NS; cc++) jr[NV + cc] -= be1 * s1 * L.x[cc];
+#pragma unroll
+            for (int cc = 0; cc < 12 * NS; cc++) s2 += jr[NV + cc] * L.x[24 + cc];
+#pragma unroll
+            for (int cc = 0; cc < 12 * NS; cc++) jr[NV + cc] -= be2 * s2 * L.x[24 + cc];
+          }
+          if (lane < 6) { // column of B = J^T CE^T: the same two (symmetric) factors, in the same order
+            T fc[12 * NS];
+#pragma unroll
+            for (int cc = 0; cc < 12 * NS; cc++) fc[cc] = fcl[lane * 12 * NS + cc];
+            T s1 = 0, s2 = 0;
+#pragma unroll
+            for (int cc = 0; cc < 12 * NS; cc++) s1 += fc[cc] * L.x[cc];
+#pragma unroll
+            for (int cc = 0; cc < 12 * NS; cc++) fc[cc] -= be1 * s1 * L.x[cc];
+#pragma unroll
+            for (int cc = 0; cc < 12 * NS; cc++) s2 += fc[cc] * L.x[24 + cc];
+#pragma unroll
+            for (int cc = 0; cc < 12 * NS; cc++) fc[cc] -= be2 * s2 * L.x[24 + cc];
+#pragma unroll
+            for (int cc = 0; cc < 12 * NS; cc++) fcl[lane * 12 * NS + cc] = fc[cc];
+          }
+          c1 += w_cop * wave_sum(A0 * A0 + A1 * A1); // trace of the Hessian (tolerance scale only)
+          __syncthreads();
         }
-        const T al1 = wave_sum(t0 * t0), a12 = wave_sum(t0 * t1);
-        const T be1 = al1 > tiny ? (1 - T(1) / sqrt(1 + w_cop * al1)) / al1 : T(0);
-        const T bq = t1 - be1 * a12 * t0;
-        const T al2 = wave_sum(bq * bq);
-        const T be2 = al2 > tiny ? (1 - T(1) / sqrt(1 + w_cop * al2)) / al2 : T(0);
-        __syncthreads();
-        if (isf) { L.x[col] = t0; L.x[24 + col] = bq; }
-        __syncthreads();
-        if (isf) { // row of J: j0 (I - b1 a1 a1^T)(I - b2 b b^T)
-          T s1 = 0, s2 = 0;
-#pragma unroll
-          for (int cc = 0; cc < 12 * NS; cc++) s1 += jr[NV + cc] * L.x[cc];
-#pragma unroll
-          for (int cc = 0; cc < 12 * NS; cc++) jr[NV + cc] -= be1 * s1 * L.x[cc];
-#pragma unroll
-          for (int cc = 0; cc < 12 * NS; cc++) s2 += jr[NV + cc] * L.x[24 + cc];
-#pragma unroll
-          for (int cc = 0; cc < 12 * NS; cc++) jr[NV + cc] -= be2 * s2 * L.x[24 + cc];
-        }
-        if (lane < 6) { // column of B = J^T CE^T: the same two (symmetric) factors, in the same order
-          T s1 = 0, s2 = 0;
-#pragma unroll
-          for (int cc = 0; cc < 12 * NS; cc++) s1 += bc[NV + cc] * L.x[cc];
-#pragma unroll
-          for (int cc = 0; cc < 12 * NS; cc++) bc[NV + cc] -= be1 * s1 * L.x[cc];
-#pragma unroll
-          for (int cc = 0; cc < 12 * NS; cc++) s2 += bc[NV + cc] * L.x[24 + cc];
-#pragma unroll
-          for (int cc = 0; cc < 12 * NS; cc++) bc[NV + cc] -= be2 * s2 * L.x[24 + cc];
-        }
-        c1 += w_cop * wave_sum(A0 * A0 + A1 * A1); // trace of the Hessian (tolerance scale only)
-        __syncthreads();
       }
+      // rows of the force block go to their group's lane
+      if (bl && col < 6) {
+#pragma unroll
+        for (int j = 0; j < GS; j++) {
+          const int row = grp * GS + j;
+          if (row >= NV && row < NN) bs[j] = fcl[col * 12 * NS + row - NV];
+        }
+      }
+      __syncthreads(); // (the sweep below writes the row buffer)
     }
     TSIDB_STAMP(5);
-    // ---- Householder QR of B (columns in lanes 0..p-1) applied to J (rows in lanes 0..n-1)
+    // ---- Householder QR of B (column c on lanes c + PP g) applied to J (rows in lanes 0..n-1)
     T R_norm = 1;
     bool degenerate = false;
+    T xeq = lane < NV ? x0 : T(0);
 #pragma unroll
     for (int k = 0; k < PP; k++) {
+      const int gk = k / GS, sk = k % GS; // the group and slot that hold row k (compile-time after unrolling)
       {
-        // lane k owns column k: alpha, tail norm, reflector scale
-        T sig = 0;
+        // tail norm of column k: each of its lanes sums its own rows > k
+        T sig_hi = 0, sig_all = 0;
 #pragma unroll
-        for (int i = k + 1; i < NN; i++) sig += bc[i] * bc[i];
-        const T alpha = rdlane(bc[k], k), sigma = rdlane(sig, k);
+        for (int j = 0; j < GS; j++) {
+          const T sq = bs[j] * bs[j];
+          sig_all += sq;
+          if (j > sk) sig_hi += sq;
+        }
+        T sigma = rdlane(sig_hi, k + PP * gk);
+#pragma unroll
+        for (int g = 0; g < G; g++)
+          if (g > gk) sigma += rdlane(sig_all, k + PP * g);
+        const T alpha = rdlane(bs[sk], k + PP * gk);
         T dkk = alpha;
         if (sigma > 0) {
           const T nrm = sqrt(alpha * alpha + sigma);
           const T v0 = alpha + (alpha >= 0 ? nrm : -nrm);
           const T beta = T(2) / (v0 * v0 + sigma);
           dkk = alpha >= 0 ? -nrm : nrm;
-          // s = v . b_col (lanes > k), w = J_row . v (all lanes)
-          T sb = v0 * bc[k], wj = v0 * jr[k], sb1 = 0, wj1 = 0;
+          // s = v . b_col: lane (c, g) sums the rows of its group (sbg[g] is meaningful on group g's lanes only);
+          // w = J_row . v (all lanes)
+          T sbg[G], wj = v0 * jr[k], wj1 = 0;
+#pragma unroll
+          for (int g = 0; g < G; g++) sbg[g] = 0;
+          sbg[gk] = v0 * bs[sk];
 #pragma unroll
           for (int i = k + 1; i < NN; i++) {
-            const T vi = rdlane(bc[i], k);
-            if (i & 1) { sb1 += vi * bc[i]; wj1 += vi * jr[i]; }
-            else { sb += vi * bc[i]; wj += vi * jr[i]; }
+            const int gi = i / GS, si = i % GS;
+            const T vi = rdlane(bs[si], k + PP * gi);
+            sbg[gi] += vi * bs[si];
+            if (i & 1) { wj1 += vi * jr[i]; ORDER_PIN2(sbg[gi], wj1); }
+            else { wj += vi * jr[i]; ORDER_PIN2(sbg[gi], wj); }
           }
-          sb = (sb + sb1) * beta; wj = (wj + wj1) * beta;
-          const bool upd = lane > k; // columns <= k are final (their rows >= k are already zero)
+          const T sbm = grp == 0 ? sbg[0] : (grp == 1 ? sbg[1] : sbg[2]);
+          T sb = bcast(sbm, col) + bcast(sbm, col + PP) + bcast(sbm, col + 2 * PP);
+          sb *= beta;
+          wj = (wj + wj1) * beta;
+          const bool upd = bl && col > k; // columns <= k are final (their rows >= k are already zero)
+          T sg[G];
+#pragma unroll
+          for (int g = 0; g < G; g++) sg[g] = (upd && grp == g) ? sb : T(0);
           jr[k] -= wj * v0;
-          if (upd) bc[k] -= sb * v0;
+          bs[sk] -= sg[gk] * v0;
+          // the reflector is READ AGAIN from lane k's registers: left to itself the compiler keeps the first loop's
+          // NN broadcast values (2 SGPRs each) for this loop, i.e. spills them to VGPR lanes with v_writelane and
+          // reloads them with v_readlane - three times the instructions of reading them again, and the spill lanes
+          // were what pushed the kernel over its VGPR budget (3 800 SGPR spills -> see DESIGN.md section 4)
+#pragma unroll
+          for (int j = 0; j < GS; j++) asm volatile("" : "+v"(bs[j]));
 #pragma unroll
           for (int i = k + 1; i < NN; i++) {
-            const T vi = rdlane(bc[i], k); // lane k's column is untouched until the loop ends
+            const int gi = i / GS, si = i % GS;
+            const T vi = rdlane(bs[si], k + PP * gi); // column k's lanes are untouched until the loop ends (sg = 0 there)
             jr[i] -= wj * vi;
-            if (upd) bc[i] -= sb * vi;
+            bs[si] -= sg[gi] * vi;
+            ORDER_PIN2(jr[i], bs[si]);
           }
-          if (lane == k) {
-            bc[k] = dkk;
+          if (bl && col == k) { // column k of R: the diagonal, zeros below
 #pragma unroll
-            for (int i = k + 1; i < NN; i++) bc[i] = 0;
+            for (int j = 0; j < GS; j++)
+              if (grp > gk || (grp == gk && j > sk)) bs[j] = 0;
+            if (grp == gk) bs[sk] = dkk;
           }
         }
         const T ad = fabs(dkk);
@@ -919,14 +1001,21 @@ __device__ __forceinline__ void tick_qp(const DevModel<T> &m, TickLds<T> &L, QpC
         if (ad > R_norm) R_norm = ad;
       }
     }
-    // ---- R^T t = -c (forward), x = x0 + J[:, :p] t  (the equality multipliers u = R^-1 t are not needed)
-    T tacc = -ck, tv[PP];
+    // ---- R^T t = -c (forward), x = x0 + J[:, :p] t  (the equality multipliers u = R^-1 t are not needed).
+    //      R[i][c] sits on lane c + PP g(i): tg[g] is column c's running sum over the rows of group g
+    T tg[G], tv[PP];
+    tg[0] = -ck;
+#pragma unroll
+    for (int g = 1; g < G; g++) tg[g] = 0;
 #pragma unroll
     for (int i = 0; i < PP; i++) {
-      tv[i] = rdlane(tacc, i) / rdlane(bc[i], i);
-      tacc -= bc[i] * tv[i];
+      const int gi = i / GS, si = i % GS;
+      T num = rdlane(tg[0], i);
+#pragma unroll
+      for (int g = 1; g < G; g++) num += rdlane(tg[g], i + PP * g);
+      tv[i] = num / rdlane(bs[si], i + PP * gi);
+      tg[gi] -= bs[si] * tv[i];
     }
-    T xeq = lane < NV ? x0 : T(0);
 #pragma unroll
     for (int k = 0; k < PP; k++) xeq += jr[k] * tv[k];
     TSIDB_STAMP(6);
@@ -1079,32 +1168,41 @@ __device__ __forceinline__ void tsid_tick_env(const DevModel<T> &m, TickLds<T> &
     }
   }
   if (lane >= NV) gi = 0;
+  // (`lane` is re-read through an empty asm at each phase: the lane == j masks of one unrolled phase, 26 SGPR pairs,
+  //  are otherwise kept for the next phase's comparisons, i.e. spilled to VGPR lanes and reloaded - a v_cmp is cheaper)
+  int ln = lane;
+  asm volatile("" : "+v"(ln));
+  T dg = 0; // this lane's diagonal entry
 #pragma unroll
   for (int j = 0; j < NV; j++)
-    if (lane == j) a[j] += reg + (j >= 6 ? w_post : T(0));
-  T c1 = 0;
-#pragma unroll
-  for (int j = 0; j < NV; j++) c1 += rdlane(a[j], j);
-  c1 += T(c.nslot) * m.Hf_trace;
+    if (ln == j) { a[j] += reg + (j >= 6 ? w_post : T(0)); dg = a[j]; }
+  T c1 = wave_sum(dg) + T(c.nslot) * m.Hf_trace; // trace (one DPP reduction instead of 26 broadcasts)
 
   int qp_status = -1, qp_iters = 0;
   TSIDB_STAMP(3);
   // ---- Cholesky in registers (right-looking; lane i holds row i of L in a[0..i]); rd[k] = 1/L[k][k]
-  bool spd = true;
-  T rd[NV];
+  T rdv = 0; // lane k: 1 / L[k][k]
+  int notspd = 0; // (a VGPR flag, pinned per pivot: 26 compare masks kept to be and-ed at the end are 52 SGPRs)
+  asm volatile("" : "+v"(ln));
 #pragma unroll
   for (int k = 0; k < NV; k++) {
     const T akk = rdlane(a[k], k);
-    if (!(akk > 0)) spd = false;
+    notspd = akk > 0 ? notspd : 1;
+    asm volatile("" : "+v"(notspd));
     const T rk = rsqrt_t(akk > 0 ? akk : T(1));
-    rd[k] = rk;
-    const T lik = lane == k ? akk * rk : a[k] * rk;
+    if (ln == k) rdv = rk;
+    const T lik = ln == k ? akk * rk : a[k] * rk;
     a[k] = lik;
 #pragma unroll
     for (int j = k + 1; j < NV; j++) a[j] -= lik * rdlane(lik, j);
   }
   TSIDB_STAMP(4);
-  tick_qp<T, NS, COP>(m, L, c, lane, a, rd, gi, c1, spd, cop_ref, qp_status, qp_iters);
+  // (the substitutions broadcast L's entries again: carried over from the factorisation they would be 650 SGPRs,
+  //  i.e. spilled to VGPR lanes and reloaded - more instructions than reading them again)
+#pragma unroll
+  for (int k = 0; k < NV; k++) asm volatile("" : "+v"(a[k]));
+  const bool spd = notspd == 0;
+  tick_qp<T, NS, COP>(m, L, c, lane, a, rdv, gi, c1, spd, cop_ref, qp_status, qp_iters);
   int status = qp_status, iters = qp_iters;
 
   TSIDB_STAMP(8);
