@@ -81,21 +81,34 @@ __device__ __forceinline__ int sym_idx(int i, int j) { // packed upper index of 
 // per-pivot LDS round trip is exposed.
 template <typename T, bool DENSE>
 __device__ __forceinline__ T chol26_solve(T (&a)[NV], T rhs, int lane, bool &spd) {
-  spd = true;
+  int ln = lane; // (re-read here: the lane < k / lane == k masks are not kept from one inlined copy of this routine to the next)
+  asm volatile("" : "+v"(ln));
+  int notspd = 0; // (a VGPR flag pinned per pivot: the 26 compare masks kept to be and-ed at the end are 52 SGPRs)
   T rd[NV]; // 1 / U[k][k], wave-uniform
 #pragma unroll
   for (int t = 0; t < NV; t++) {
     const int k = NV - 1 - t;
     const T akk = rdlane(a[k], k);
-    if (!(akk > 0)) spd = false;
+    notspd = akk > 0 ? notspd : 1;
+    asm volatile("" : "+v"(notspd));
     const T rk = rsqrt_t(akk > 0 ? akk : T(1));
     rd[k] = rk;
-    const T uik = lane < k ? a[k] * rk : (lane == k ? akk * rk : T(0));
+    T uik = ln < k ? a[k] * rk : (ln == k ? akk * rk : T(0));
     a[k] = uik;
 #pragma unroll
     for (int j = 0; j < k; j++)
-      if (DENSE || ((MJ_DOFANC[k] >> j) & 1u)) a[j] -= uik * rdlane(uik, j);
+      if (DENSE || ((MJ_DOFANC[k] >> j) & 1u)) {
+        a[j] -= uik * rdlane(uik, j);
+        // (each broadcast is consumed before the next is read: issued as one burst, the row's broadcasts are 2 SGPRs
+        //  each that the compiler parks in VGPR lanes - v_writelane / v_readlane - until their turn)
+        asm volatile("" : "+v"(uik), "+v"(a[j]));
+      }
   }
+  spd = notspd == 0;
+  // the solves broadcast U's entries again: carried over from the factorisation (the compiler's choice) they are ~350
+  // SGPRs, i.e. spilled to VGPR lanes with v_writelane and reloaded - more instructions than reading them again
+#pragma unroll
+  for (int k = 0; k < NV; k++) asm volatile("" : "+v"(a[k]));
   // U y = rhs (descendants first; lane k contributes y_k), then U^T x = y (ancestors first, wave-uniform)
   T acc = rhs, y[NV];
 #pragma unroll
@@ -108,12 +121,15 @@ __device__ __forceinline__ T chol26_solve(T (&a)[NV], T rhs, int lane, bool &spd
 #pragma unroll
   for (int t = NV - 1; t >= 0; t--) {
     const int k = NV - 1 - t;
-    T s0 = y[k];
+    T s0 = y[k], ak = a[k];
 #pragma unroll
     for (int i = 0; i < k; i++)
-      if (DENSE || ((MJ_DOFANC[k] >> i) & 1u)) s0 -= rdlane(a[k], i) * xs[i];
+      if (DENSE || ((MJ_DOFANC[k] >> i) & 1u)) {
+        s0 -= rdlane(ak, i) * xs[i];
+        asm volatile("" : "+v"(ak), "+v"(s0)); // (as above)
+      }
     xs[k] = s0 * rd[k];
-    if (lane == k) x = xs[k];
+    if (ln == k) x = xs[k];
   }
   return x;
 }
