@@ -95,13 +95,15 @@ __device__ __forceinline__ T chol26_solve(T (&a)[NV], T rhs, int lane, bool &spd
     rd[k] = rk;
     T uik = ln < k ? a[k] * rk : (ln == k ? akk * rk : T(0));
     a[k] = uik;
+    int cnt = 0; // (compile-time after unrolling)
 #pragma unroll
     for (int j = 0; j < k; j++)
       if (DENSE || ((MJ_DOFANC[k] >> j) & 1u)) {
         a[j] -= uik * rdlane(uik, j);
-        // (each broadcast is consumed before the next is read: issued as one burst, the row's broadcasts are 2 SGPRs
-        //  each that the compiler parks in VGPR lanes - v_writelane / v_readlane - until their turn)
-        asm volatile("" : "+v"(uik), "+v"(a[j]));
+        // (broadcasts are consumed in groups of four before the next are read: issued as one burst, the row's broadcasts
+        //  are 2 SGPRs each that the compiler parks in VGPR lanes - v_writelane / v_readlane - until their turn; one at
+        //  a time, every FMA waits out the v_readlane -> VALU hazard)
+        if ((++cnt & 3) == 0) asm volatile("" : "+v"(uik), "+v"(a[j]));
       }
   }
   spd = notspd == 0;
@@ -121,14 +123,16 @@ __device__ __forceinline__ T chol26_solve(T (&a)[NV], T rhs, int lane, bool &spd
 #pragma unroll
   for (int t = NV - 1; t >= 0; t--) {
     const int k = NV - 1 - t;
-    T s0 = y[k], ak = a[k];
+    T s0 = y[k], s1 = 0, ak = a[k]; // two chains: a dependent f64 FMA waits for its predecessor
+    int cnt = 0;
 #pragma unroll
     for (int i = 0; i < k; i++)
       if (DENSE || ((MJ_DOFANC[k] >> i) & 1u)) {
-        s0 -= rdlane(ak, i) * xs[i];
-        asm volatile("" : "+v"(ak), "+v"(s0)); // (as above)
+        if (cnt & 1) s1 -= rdlane(ak, i) * xs[i];
+        else s0 -= rdlane(ak, i) * xs[i];
+        if ((++cnt & 3) == 0) asm volatile("" : "+v"(ak), "+v"(s0), "+v"(s1)); // (as above)
       }
-    xs[k] = s0 * rd[k];
+    xs[k] = (s0 + s1) * rd[k];
     if (ln == k) x = xs[k];
   }
   return x;

@@ -341,6 +341,8 @@ __device__ __forceinline__ void se3_rhs(const TickLds<T> &L, int f, const T *ref
 }
 
 #define ORDER_PIN2(x, y) asm volatile("" : "+v"(x), "+v"(y))
+#define ORDER_PIN4(x, y, z, w) asm volatile("" : "+v"(x), "+v"(y), "+v"(z), "+v"(w)) // (two steps at a time: hipcc pads an
+// asm statement's outputs with one wait state before the next VALU that touches them, so a pin is not entirely free)
 
 // --------------------------------------------------------------------------- QP pieces
 __device__ __forceinline__ int rcol(int c) { return c * (c + 1) / 2; } // packed upper-triangular column start
@@ -736,7 +738,7 @@ __device__ __forceinline__ void tick_qp(const DevModel<T> &m, TickLds<T> &L, QpC
   // then the other, keeping all the loop's broadcast values alive in between - ~100 SGPRs it does not have, so it spills
   // each to a VGPR lane (v_writelane + wait states) and reloads it (v_readlane): 3 800 spill sites in this kernel, whose
   // spill VGPRs in turn pushed the vector registers over budget.  Volatile asms keep their order, so pinning both
-  // accumulators after each step keeps the two uses adjacent.  Costs no instruction.
+  // accumulators after each step keeps the two uses adjacent.  Costs no instruction (one wait state at most).
   // ---- three forward substitutions with L share its broadcast entries:
   //   y  = L^-1 (-g)                      (uniform, lane i contributes y_i)
   //   xr = L^-1 e_lane                    (column `lane` of L^-1 = row `lane` of J0 = L^-T)
@@ -777,8 +779,8 @@ __device__ __forceinline__ void tick_qp(const DevModel<T> &m, TickLds<T> &L, QpC
         for (int k = 0; k < i; k++) {
           const T lik = rdlane(a[k], i);
           // ORDER_PIN: both uses of a broadcast value stay together (see tick_qp's header)
-          if (k & 1) { xs1 -= lik * jr[k]; bsum1 -= lik * bc[k]; ORDER_PIN2(xs1, bsum1); }
-          else { xs -= lik * jr[k]; bsum -= lik * bc[k]; ORDER_PIN2(xs, bsum); }
+          if (k & 1) { xs1 -= lik * jr[k]; bsum1 -= lik * bc[k]; ORDER_PIN4(xs, bsum, xs1, bsum1); }
+          else { xs -= lik * jr[k]; bsum -= lik * bc[k]; }
         }
         jr[i] = (xs + xs1) * rdi;
         bc[i] = (bsum + bsum1) * rdi;
@@ -962,8 +964,8 @@ __device__ __forceinline__ void tick_qp(const DevModel<T> &m, TickLds<T> &L, QpC
             const int gi = i / GS, si = i % GS;
             const T vi = rdlane(bs[si], k + PP * gi);
             sbg[gi] += vi * bs[si];
-            if (i & 1) { wj1 += vi * jr[i]; ORDER_PIN2(sbg[gi], wj1); }
-            else { wj += vi * jr[i]; ORDER_PIN2(sbg[gi], wj); }
+            if (i & 1) { wj1 += vi * jr[i]; ORDER_PIN4(sbg[gi], sbg[(i - 1) / GS], wj, wj1); }
+            else { wj += vi * jr[i]; }
           }
           const T sbm = grp == 0 ? sbg[0] : (grp == 1 ? sbg[1] : sbg[2]);
           T sb = bcast(sbm, col) + bcast(sbm, col + PP) + bcast(sbm, col + 2 * PP);
@@ -987,7 +989,7 @@ __device__ __forceinline__ void tick_qp(const DevModel<T> &m, TickLds<T> &L, QpC
             const T vi = rdlane(bs[si], k + PP * gi); // column k's lanes are untouched until the loop ends (sg = 0 there)
             jr[i] -= wj * vi;
             bs[si] -= sg[gi] * vi;
-            ORDER_PIN2(jr[i], bs[si]);
+            if (i & 1) ORDER_PIN4(jr[i], bs[si], jr[i - 1], bs[(i - 1) % GS]);
           }
           if (bl && col == k) { // column k of R: the diagonal, zeros below
 #pragma unroll
@@ -1143,14 +1145,30 @@ __device__ __forceinline__ void tsid_tick_env(const DevModel<T> &m, TickLds<T> &
 #pragma unroll
   for (int r = 0; r < 3; r++) gi -= w_com * jt[12 + r] * L.k.acomr[r];
   if (lane >= 6 && lane < NV) gi -= w_post * L.k.apost[lane - 6];
+  // H[i][j] = sum_r w_r J_r[i] J_r[j]: lane i keeps w_r J_r[i]; J_r[j] is read back from the Jacobians in LDS at a
+  // wave-uniform address (one ds_read2_b64 per two values, in the LDS pipe beside the FMAs) instead of a v_readlane
+  // pair + wait states per value from the neighbour's registers: 390 broadcast values per tick
+  {
+    T wjt[15];
 #pragma unroll
-  for (int j = 0; j < NV; j++) {
-    T acc = 0;
+    for (int r = 0; r < 12; r++) wjt[r] = w_foot * jt[r];
 #pragma unroll
-    for (int r = 0; r < 12; r++) acc += w_foot * jt[r] * rdlane(jt[r], j);
+    for (int r = 0; r < 3; r++) wjt[12 + r] = w_com * jt[12 + r];
 #pragma unroll
-    for (int r = 0; r < 3; r++) acc += w_com * jt[12 + r] * rdlane(jt[12 + r], j);
-    a[j] = acc;
+    for (int j = 0; j < NV; j++) {
+      T acc = 0, acc1 = 0;
+#pragma unroll
+      for (int r = 0; r < 12; r++) {
+        if (r & 1) acc1 += wjt[r] * L.k.Jf[r * LDF + j];
+        else acc += wjt[r] * L.k.Jf[r * LDF + j];
+      }
+#pragma unroll
+      for (int r = 0; r < 3; r++) {
+        if (r & 1) acc1 += wjt[12 + r] * L.k.Jcom[r * LDF + j];
+        else acc += wjt[12 + r] * L.k.Jcom[r * LDF + j];
+      }
+      a[j] = acc + acc1;
+    }
   }
   const T w_am = m.params[P_W_AM];
   if (w_am != 0) { // optional angular-momentum rows; wave-uniform branch
