@@ -9,8 +9,8 @@ G=gpurun_out
 cp $G/${TAG}_bench.json profiles/${RND}_final_bench.json
 cp $G/${TAG}_bench_driver_window.json profiles/${RND}_final_bench_driver_window.json
 cp $G/${TAG}_bench_no_overlap.json profiles/${RND}_final_bench_no_overlap.json
-cp $G/${TAG}_trace/*/*_kernel_stats.csv profiles/${RND}_final_kernel_stats_overlap.csv
-cp $G/${TAG}_trace_serial/*/*_kernel_stats.csv profiles/${RND}_final_kernel_stats_serial.csv
+cp "$(ls -S $G/${TAG}_trace/*/*_kernel_stats.csv | head -1)" profiles/${RND}_final_kernel_stats_overlap.csv   # (largest: the bench process, not a helper child)
+cp "$(ls -S $G/${TAG}_trace_serial/*/*_kernel_stats.csv | head -1)" profiles/${RND}_final_kernel_stats_serial.csv
 cp $G/${TAG}_bench_under_rocprof.json profiles/${RND}_final_bench_under_rocprof_overlap.json
 cp $G/${TAG}_bench_under_rocprof_serial.json profiles/${RND}_final_bench_under_rocprof_serial.json
 python3 tools/pmc_summary.py $G/${TAG}_pmc --last 100 --traffic-json profiles/pmc_traffic.json > profiles/${RND}_final_pmc_walk_f64_last100.txt

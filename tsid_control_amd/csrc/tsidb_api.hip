@@ -28,8 +28,9 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2))) void 
                                                   int *status, T *obs, int obs_ld, T *frames, int *info, const T *qpos_sim,
                                                   const T *qvel_sim, const T *cop_ref) {
   __shared__ TickLds<T> L;
-  const int e = blockIdx.x, lane = threadIdx.x;
-  if (e >= n) return;
+  const int lane = threadIdx.x;
+  if ((int)blockIdx.x >= n) return;
+  const int e = env_of_block(blockIdx.x, n);
   const size_t E = (size_t)e;
   const int ns = (cact[E * 2] != 0) + (cact[E * 2 + 1] != 0);
   {
@@ -79,8 +80,9 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2))) void 
                                               T *qacc_ws, const T *env_params, const T *terrain, const T *motor_tau, T *qacc, int *ncon,
                                               int *con, int *info) {
   __shared__ SimLds<T> L;
-  const int e = blockIdx.x, lane = threadIdx.x;
-  if (e >= n) return;
+  const int lane = threadIdx.x;
+  if ((int)blockIdx.x >= n) return;
+  const int e = env_of_block(blockIdx.x, n);
   const size_t E = (size_t)e;
   {
     // non-finite sim state / targets, or a sim state that has diverged (sum of |qpos| + |qvel| beyond SIM_STATE_BOUND:
@@ -110,8 +112,9 @@ template <typename T>
 __global__ __launch_bounds__(WAVE) void k_rbd(const DevModel<T> *__restrict__ mp, int n, const T *q, const T *v, T *M, T *hb,
                                               T *Jcom, T *Jf, T *oMf, T *com) {
   __shared__ TickLds<T> L;
-  const int e = blockIdx.x, lane = threadIdx.x;
-  if (e >= n) return;
+  const int lane = threadIdx.x;
+  if ((int)blockIdx.x >= n) return;
+  const int e = env_of_block(blockIdx.x, n);
   const size_t E = (size_t)e;
   if (lane < NQ) L.qs[lane] = q[E * NQ + lane];
   if (lane < NV) L.vs[lane] = v[E * NV + lane];

@@ -192,6 +192,16 @@ __device__ __forceinline__ void sincos_t(double x, double &s, double &c) {
   c = ((q + 1) & 2) ? -c0 : c0;
 }
 
+// Workgroup -> env.  The hardware deals consecutive workgroups round-robin to the 8 XCDs (one L2 each); with env =
+// blockIdx, neighbouring envs - whose 160..536-byte rows share 64 / 128-byte lines at their ends - are written from
+// different L2s, and each writes its part of the shared line back on its own (k_tick WRITE_SIZE 2.4 x the bytes stored).
+// Give XCD x the contiguous env range [start_x, start_x + count_x) instead: lines are shared only at the 7 range borders.
+__device__ __forceinline__ int env_of_block(int b, int n) {
+  constexpr int NXCD = 8;
+  const int x = b % NXCD, i = b / NXCD, q = n / NXCD, r = n % NXCD;
+  return x * q + (x < r ? x : r) + i;
+}
+
 // a sim state with sum |qpos| + sum |qvel| beyond this (m, rad, m/s, rad/s) has diverged: the step is skipped and flagged
 constexpr double SIM_STATE_BOUND = 1e6;
 template <typename T> struct Eps;
