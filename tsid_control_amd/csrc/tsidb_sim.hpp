@@ -95,16 +95,27 @@ __device__ __forceinline__ T chol26_solve(T (&a)[NV], T rhs, int lane, bool &spd
     rd[k] = rk;
     T uik = ln < k ? a[k] * rk : (ln == k ? akk * rk : T(0));
     a[k] = uik;
-    int cnt = 0; // (compile-time after unrolling)
+    // Broadcasts four at a time: READ four (eight v_readlane), then the four FMAs.  Left alone the compiler either
+    // issues the whole row's broadcasts as one burst (2 SGPRs each, parked in VGPR lanes with v_writelane / v_readlane
+    // until their turn) or one at a time, v_readlane x2 - s_nop 1 - v_fma, where every FMA waits out the
+    // v_readlane -> VALU hazard.  The empty asm takes the four values as SGPR inputs (so they exist before it) and
+    // "changes" uik (so the FMAs and the next reads come after it) and the previous group's last result (so that group's
+    // FMAs come before it).
+    int jl = -1; // (compile-time after unrolling)
 #pragma unroll
-    for (int j = 0; j < k; j++)
-      if (DENSE || ((MJ_DOFANC[k] >> j) & 1u)) {
-        a[j] -= uik * rdlane(uik, j);
-        // (broadcasts are consumed in groups of four before the next are read: issued as one burst, the row's broadcasts
-        //  are 2 SGPRs each that the compiler parks in VGPR lanes - v_writelane / v_readlane - until their turn; one at
-        //  a time, every FMA waits out the v_readlane -> VALU hazard)
-        if ((++cnt & 3) == 0) asm volatile("" : "+v"(uik), "+v"(a[j]));
-      }
+    for (int j0 = 0; j0 < k; j0 += 4) {
+      const bool p0 = DENSE || ((MJ_DOFANC[k] >> j0) & 1u), p1 = j0 + 1 < k && (DENSE || ((MJ_DOFANC[k] >> (j0 + 1)) & 1u)),
+                 p2 = j0 + 2 < k && (DENSE || ((MJ_DOFANC[k] >> (j0 + 2)) & 1u)), p3 = j0 + 3 < k && (DENSE || ((MJ_DOFANC[k] >> (j0 + 3)) & 1u));
+      if (!(p0 || p1 || p2 || p3)) continue;
+      const T u0 = p0 ? rdlane(uik, j0) : T(0), u1 = p1 ? rdlane(uik, j0 + 1) : T(0), u2 = p2 ? rdlane(uik, j0 + 2) : T(0),
+              u3 = p3 ? rdlane(uik, j0 + 3) : T(0);
+      if (jl >= 0) asm volatile("" : "+v"(uik), "+v"(a[jl]) : "s"(u0), "s"(u1), "s"(u2), "s"(u3));
+      else asm volatile("" : "+v"(uik) : "s"(u0), "s"(u1), "s"(u2), "s"(u3));
+      if (p0) { a[j0] -= uik * u0; jl = j0; }
+      if (p1) { a[j0 + 1] -= uik * u1; jl = j0 + 1; }
+      if (p2) { a[j0 + 2] -= uik * u2; jl = j0 + 2; }
+      if (p3) { a[j0 + 3] -= uik * u3; jl = j0 + 3; }
+    }
   }
   spd = notspd == 0;
   // the solves broadcast U's entries again: carried over from the factorisation (the compiler's choice) they are ~350
@@ -124,14 +135,19 @@ __device__ __forceinline__ T chol26_solve(T (&a)[NV], T rhs, int lane, bool &spd
   for (int t = NV - 1; t >= 0; t--) {
     const int k = NV - 1 - t;
     T s0 = y[k], s1 = 0, ak = a[k]; // two chains: a dependent f64 FMA waits for its predecessor
-    int cnt = 0;
 #pragma unroll
-    for (int i = 0; i < k; i++)
-      if (DENSE || ((MJ_DOFANC[k] >> i) & 1u)) {
-        if (cnt & 1) s1 -= rdlane(ak, i) * xs[i];
-        else s0 -= rdlane(ak, i) * xs[i];
-        if ((++cnt & 3) == 0) asm volatile("" : "+v"(ak), "+v"(s0), "+v"(s1)); // (as above)
-      }
+    for (int i0 = 0; i0 < k; i0 += 4) { // (broadcasts four at a time, as above)
+      const bool p0 = DENSE || ((MJ_DOFANC[k] >> i0) & 1u), p1 = i0 + 1 < k && (DENSE || ((MJ_DOFANC[k] >> (i0 + 1)) & 1u)),
+                 p2 = i0 + 2 < k && (DENSE || ((MJ_DOFANC[k] >> (i0 + 2)) & 1u)), p3 = i0 + 3 < k && (DENSE || ((MJ_DOFANC[k] >> (i0 + 3)) & 1u));
+      if (!(p0 || p1 || p2 || p3)) continue;
+      const T u0 = p0 ? rdlane(ak, i0) : T(0), u1 = p1 ? rdlane(ak, i0 + 1) : T(0), u2 = p2 ? rdlane(ak, i0 + 2) : T(0),
+              u3 = p3 ? rdlane(ak, i0 + 3) : T(0);
+      asm volatile("" : "+v"(ak), "+v"(s0), "+v"(s1) : "s"(u0), "s"(u1), "s"(u2), "s"(u3));
+      if (p0) s0 -= u0 * xs[i0];
+      if (p1) s1 -= u1 * xs[i0 + 1];
+      if (p2) s0 -= u2 * xs[i0 + 2];
+      if (p3) s1 -= u3 * xs[i0 + 3];
+    }
     xs[k] = (s0 + s1) * rd[k];
     if (ln == k) x = xs[k];
   }
