@@ -776,11 +776,12 @@ __device__ __forceinline__ void tick_qp(const DevModel<T> &m, TickLds<T> &L, QpC
         T xs = ln == i ? T(1) : T(0), xs1 = 0;
         T bsum = bl ? (isbase ? L.Dyn[crow * LDD + i] : L.k.Jf[crow * LDF + i]) : T(0), bsum1 = 0;
 #pragma unroll
-        for (int k = 0; k < i; k++) {
-          const T lik = rdlane(a[k], i);
-          // ORDER_PIN: both uses of a broadcast value stay together (see tick_qp's header)
-          if (k & 1) { xs1 -= lik * jr[k]; bsum1 -= lik * bc[k]; ORDER_PIN4(xs, bsum, xs1, bsum1); }
-          else { xs -= lik * jr[k]; bsum -= lik * bc[k]; }
+        for (int k0 = 0; k0 < i; k0 += 2) { // two broadcasts READ, then their four FMAs (see tick_qp's header)
+          const bool p1 = k0 + 1 < i;
+          const T l0 = rdlane(a[k0], i), l1 = p1 ? rdlane(a[p1 ? k0 + 1 : 0], i) : T(0);
+          asm volatile("" : "+v"(xs), "+v"(bsum), "+v"(xs1), "+v"(bsum1) : "s"(l0), "s"(l1));
+          xs -= l0 * jr[k0]; bsum -= l0 * bc[k0];
+          if (p1) { xs1 -= l1 * jr[k0 + 1]; bsum1 -= l1 * bc[k0 + 1]; }
         }
         jr[i] = (xs + xs1) * rdi;
         bc[i] = (bsum + bsum1) * rdi;
@@ -960,12 +961,14 @@ __device__ __forceinline__ void tick_qp(const DevModel<T> &m, TickLds<T> &L, QpC
           for (int g = 0; g < G; g++) sbg[g] = 0;
           sbg[gk] = v0 * bs[sk];
 #pragma unroll
-          for (int i = k + 1; i < NN; i++) {
-            const int gi = i / GS, si = i % GS;
-            const T vi = rdlane(bs[si], k + PP * gi);
-            sbg[gi] += vi * bs[si];
-            if (i & 1) { wj1 += vi * jr[i]; ORDER_PIN4(sbg[gi], sbg[(i - 1) / GS], wj, wj1); }
-            else { wj += vi * jr[i]; }
+          for (int i0 = k + 1; i0 < NN; i0 += 2) { // two reflector entries READ, then their four FMAs
+            const bool p1 = i0 + 1 < NN;
+            const int i1 = p1 ? i0 + 1 : i0, g0 = i0 / GS, s0 = i0 % GS, g1 = i1 / GS, s1 = i1 % GS;
+            const T u0 = rdlane(bs[s0], k + PP * g0), u1 = p1 ? rdlane(bs[s1], k + PP * g1) : T(0);
+            asm volatile("" : "+v"(wj), "+v"(wj1), "+v"(sbg[g0]), "+v"(sbg[g1]) : "s"(u0), "s"(u1));
+            sbg[g0] += u0 * bs[s0];
+            wj += u0 * jr[i0];
+            if (p1) { sbg[g1] += u1 * bs[s1]; wj1 += u1 * jr[i1]; }
           }
           const T sbm = grp == 0 ? sbg[0] : (grp == 1 ? sbg[1] : sbg[2]);
           T sb = bcast(sbm, col) + bcast(sbm, col + PP) + bcast(sbm, col + 2 * PP);
@@ -984,12 +987,15 @@ __device__ __forceinline__ void tick_qp(const DevModel<T> &m, TickLds<T> &L, QpC
 #pragma unroll
           for (int j = 0; j < GS; j++) asm volatile("" : "+v"(bs[j]));
 #pragma unroll
-          for (int i = k + 1; i < NN; i++) {
-            const int gi = i / GS, si = i % GS;
-            const T vi = rdlane(bs[si], k + PP * gi); // column k's lanes are untouched until the loop ends (sg = 0 there)
-            jr[i] -= wj * vi;
-            bs[si] -= sg[gi] * vi;
-            if (i & 1) ORDER_PIN4(jr[i], bs[si], jr[i - 1], bs[(i - 1) % GS]);
+          for (int i0 = k + 1; i0 < NN; i0 += 2) { // (column k's lanes are untouched until the loop ends: sg = 0 there)
+            const bool p1 = i0 + 1 < NN;
+            const int i1 = p1 ? i0 + 1 : i0, g0 = i0 / GS, s0 = i0 % GS, g1 = i1 / GS, s1 = i1 % GS;
+            const T u0 = rdlane(bs[s0], k + PP * g0), u1 = p1 ? rdlane(bs[s1], k + PP * g1) : T(0);
+            // this pair's targets and the previous pair's last result are "changed": the previous FMAs come before, these after
+            asm volatile("" : "+v"(jr[i0]), "+v"(jr[i1]), "+v"(jr[i0 - 1]), "+v"(wj) : "s"(u0), "s"(u1));
+            jr[i0] -= wj * u0;
+            bs[s0] -= sg[g0] * u0;
+            if (p1) { jr[i1] -= wj * u1; bs[s1] -= sg[g1] * u1; }
           }
           if (bl && col == k) { // column k of R: the diagonal, zeros below
 #pragma unroll
@@ -1211,8 +1217,23 @@ __device__ __forceinline__ void tsid_tick_env(const DevModel<T> &m, TickLds<T> &
     if (ln == k) rdv = rk;
     const T lik = ln == k ? akk * rk : a[k] * rk;
     a[k] = lik;
+    // broadcasts four at a time, read ahead of their FMAs (left alone: v_readlane x2 - s_nop 1 - v_fma per entry, every
+    // FMA waiting out the v_readlane -> VALU hazard).  The empty asm takes the four values as SGPR inputs, so they exist
+    // before it, and "changes" lik and the previous group's last result, so that group's FMAs come before it and this
+    // group's after.
+    T lk = lik;
 #pragma unroll
-    for (int j = k + 1; j < NV; j++) a[j] -= lik * rdlane(lik, j);
+    for (int j0 = k + 1; j0 < NV; j0 += 4) {
+      const bool p1 = j0 + 1 < NV, p2 = j0 + 2 < NV, p3 = j0 + 3 < NV;
+      const T u0 = rdlane(lk, j0), u1 = p1 ? rdlane(lk, p1 ? j0 + 1 : 0) : T(0), u2 = p2 ? rdlane(lk, p2 ? j0 + 2 : 0) : T(0),
+              u3 = p3 ? rdlane(lk, p3 ? j0 + 3 : 0) : T(0);
+      if (j0 > k + 1) asm volatile("" : "+v"(lk), "+v"(a[j0 - 1]) : "s"(u0), "s"(u1), "s"(u2), "s"(u3));
+      else asm volatile("" : "+v"(lk) : "s"(u0), "s"(u1), "s"(u2), "s"(u3));
+      a[j0] -= lk * u0;
+      if (p1) a[j0 + 1] -= lk * u1;
+      if (p2) a[j0 + 2] -= lk * u2;
+      if (p3) a[j0 + 3] -= lk * u3;
+    }
   }
   TSIDB_STAMP(4);
   // (the substitutions broadcast L's entries again: carried over from the factorisation they would be 650 SGPRs,
