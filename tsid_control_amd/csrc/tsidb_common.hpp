@@ -238,6 +238,19 @@ template <typename T> __device__ __forceinline__ T wave_sum(T v) {
   v += dpp_mov<0x143, 0xc>(v); // row_bcast31 into rows 2, 3
   return lane63(v);
 }
+// three sums at once: the DPP steps of the three values are interleaved, so that a step's v_mov_dpp pair does not wait
+// out the VALU-write -> DPP-read hazard on the sum the previous step just produced (one reduction alone: s_nop 1 per step)
+template <typename T> __device__ __forceinline__ void wave_sum3(T &a, T &b, T &c) {
+#define TSIDB_SUM3_STEP(CTRL, MASK)                                                                  \
+  {                                                                                                  \
+    const T ta = dpp_mov<CTRL, MASK>(a), tb = dpp_mov<CTRL, MASK>(b), tc = dpp_mov<CTRL, MASK>(c);   \
+    a += ta; b += tb; c += tc;                                                                       \
+  }
+  TSIDB_SUM3_STEP(0xB1, 0xf) TSIDB_SUM3_STEP(0x4E, 0xf) TSIDB_SUM3_STEP(0x141, 0xf) TSIDB_SUM3_STEP(0x140, 0xf)
+  TSIDB_SUM3_STEP(0x142, 0xa) TSIDB_SUM3_STEP(0x143, 0xc)
+#undef TSIDB_SUM3_STEP
+  a = lane63(a); b = lane63(b); c = lane63(c);
+}
 // Subtree sums of a tree numbered depth-first pre-order on lanes 0..31 (lane j = node j, `last` = last index
 // of j's subtree, v = 0 on unused lanes): an inclusive prefix scan over the lanes (row_shr 1, 2, 4, 8 within
 // the 16-lane rows, row_bcast15 into row 1), then S_j = (P[last_j] - P[j]) + v_j.  Replaces a depth loop of

@@ -1336,17 +1336,19 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
       const T Mv = mulM(L, L.xv, lane);
       if (rs.has_f) rs.fJv = search;
       if (rs.has_c) contact_rows(m, L, nfl, lane, L.xv, mu, rs.cJv);
-      T qg1 = wave_sum(lane < NV ? search * (Ma - qfs) : T(0));
-      T qg2 = wave_sum(lane < NV ? T(0.5) * search * Mv : T(0));
-      T snorm = sqrt(wave_sum(lane < NV ? search * search : T(0)));
+      T qg1 = lane < NV ? search * (Ma - qfs) : T(0), qg2 = lane < NV ? T(0.5) * search * Mv : T(0),
+        snorm = lane < NV ? search * search : T(0);
+      wave_sum3(qg1, qg2, snorm);
+      snorm = sqrt(snorm);
       if (snorm < MINVAL) break;
       const T gtol = tol * ls_tol * snorm * m.meaninertia * NV;
       auto ls_eval = [&](T alpha, T &c, T &d1, T &d2) {
         T lc, lg, lh;
         rows_eval(rs, alpha, lc, lg, lh);
-        c = alpha * alpha * qg2 + alpha * qg1 + gauss + wave_sum(lc);
-        d1 = 2 * alpha * qg2 + qg1 + wave_sum(lg);
-        d2 = 2 * qg2 + wave_sum(lh);
+        wave_sum3(lc, lg, lh);
+        c = alpha * alpha * qg2 + alpha * qg1 + gauss + lc;
+        d1 = 2 * alpha * qg2 + qg1 + lg;
+        d2 = 2 * qg2 + lh;
       };
       T c0, g1, g2, ca, alpha = 0, lo = 0, hi = INF;
       ls_eval(T(0), c0, g1, g2);
