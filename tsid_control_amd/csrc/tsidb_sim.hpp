@@ -1107,7 +1107,10 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
 
     TSIDB_STAMP(20);
     asm volatile("" ::: "memory");
-    const T tol = m.opt[2], ls_tol = m.opt[5];
+    // (float32: the solver tolerance 1e-8 is below the rounding noise of the cost, so a converged env used to pass the
+    //  improvement test by noise, build and factor a second Hessian and then find no step: the tolerance is floored at
+    //  64 ulp there - no effect in float64)
+    const T tol = m.opt[2] > 64 * Eps<T>::v ? m.opt[2] : 64 * Eps<T>::v, ls_tol = m.opt[5];
     const int maxiter = (int)m.opt[3], ls_iter = (int)m.opt[4];
     const T scale = T(1) / (m.meaninertia * NV);
     T cost = 0;
