@@ -552,6 +552,21 @@ def test_non_finite_inputs_are_contained(oracle):
     assert diff(wc.qpos[good], st["qpos"][good]) < 1e-9
 
 
+@pytest.mark.parametrize("n", [1, 7, 13, 67, 257])
+def test_every_env_is_stepped_for_any_batch_size(oracle, n):
+    """the workgroup -> env table gives each of the 8 XCDs a contiguous env range (csrc/tsidb_common.hpp: env_of_block);
+    batch sizes that are not multiples of 8 - and smaller than 8 - must still step every env exactly once"""
+    wc = make(n)
+    perturb(wc, 90 + n)
+    st = mirror(wc)
+    for _ in range(3):
+        wc.step()
+        oracle.env_step_batch(wc.params, st, nthreads=8)
+    assert np.array_equal(wc.status.cpu().numpy(), st["status"]) and int((wc.status != 0).sum()) == 0
+    assert diff(wc.tau, st["tau"]) < 1e-7 and diff(wc.q, st["q"]) < 1e-10 and diff(wc.qpos, st["qpos"]) < 1e-9
+    assert np.array_equal(wc.ncon.cpu().numpy(), st["ncon"]) and np.array_equal(wc.con_pairs.cpu().numpy(), st["con_geom"])
+
+
 def test_diverged_sim_state_is_contained(oracle):
     """A finite but absurd sim state (the reference's own standing loop drives its teleported sim to 1e150 within 700
     ticks; products of such values overflow to inf / NaN inside the step, and a NaN placement used to index the hull
