@@ -59,6 +59,10 @@ def parse():
     ap.add_argument("--envs-per-gpu", type=int, default=None, help="same as --weak --envs N")
     ap.add_argument("--dtype", choices=["f64", "f32"], default="f64")
     ap.add_argument("--workload", choices=["walk", "stand"], default="walk")
+    ap.add_argument("--closed-loop", action="store_true",
+                    help="walk workload with the loop closed (SURVEY 8f-1): the tick reads the sim state, the sim is driven by "
+                         "tau, touch-downs follow the sim's contact list (walk_planner.op3_closed_loop_walking_conf); tick and sim "
+                         "cannot overlap then")
     ap.add_argument("--robot", choices=["v1", "v0"], default="v1",
                     help="v0: the reference's second robot (robot/v0, libtsidb_v0.so; SURVEY 8f-4) - standing workload only "
                          "(the reference has no walking configuration for it)")
@@ -177,7 +181,11 @@ def run_workload(a, dev, rank, world, n, with_gather=True):
         # OP3-sized steps and walking task weights (walk_planner.op3_walking_conf explains why conf.py's
         # own values cannot walk); the sim follows the true base orientation (quirk F6a would tip it over
         # as soon as the path turns)
-        op3_walking_conf(conf)
+        if getattr(a, "closed_loop", False):
+            from tsid_control_amd.walk_planner import op3_closed_loop_walking_conf
+            op3_closed_loop_walking_conf(conf)
+        else:
+            op3_walking_conf(conf)
         conf.reference_quirks = False
     if a.tau_max_scaling is not None:
         conf.tau_max_scaling = a.tau_max_scaling
@@ -190,7 +198,10 @@ def run_workload(a, dev, rank, world, n, with_gather=True):
         lf, rf = wc.frames[0, 0, 9:11].cpu().numpy(), wc.frames[0, 1, 9:11].cpu().numpy()
         wc.posture_ref += torch.as_tensor(op3_walking_posture(), device=dev).to(wc.dtype)
         sched = WalkSchedule.from_demo_paths(n, conf, dev, wc.dtype, seed=1 + rank, q0_feet=(lf, rf),
-                                             com0=wc.com_ref[0, :3].double().cpu().numpy())
+                                             com0=wc.com_ref[0, :3].double().cpu().numpy(),
+                                             **({"foot_press": 0.0} if getattr(a, "closed_loop", False) else {}))
+        if getattr(a, "closed_loop", False):
+            sched.enable_touchdown_feedback()
         if a.dephase > 0:
             g = torch.Generator().manual_seed(7 + rank)
             sched.set_phase_offsets(torch.rand(n, generator=g, dtype=torch.float64) * a.dephase)
@@ -205,7 +216,7 @@ def run_workload(a, dev, rank, world, n, with_gather=True):
     # The sim stage of step t only needs the TSID state tick t produced, and tick t+1 does not depend on
     # sim t (the reference couples them one way, main.py:192-195): WalkController.step_pipelined() leaves
     # sim(t) running on a second HIP stream while tick(t+1) runs on the first.
-    overlap = not a.no_overlap
+    overlap = not a.no_overlap and not getattr(a, "closed_loop", False)
     s_tick = torch.cuda.current_stream(dev)
     # N > 1: the all-gather of step t's rows runs on a third stream from a two-slot snapshot, so the
     # collective's latency is off the tick stream's critical path (the next tick overwrites the rows)
@@ -222,12 +233,17 @@ def run_workload(a, dev, rank, world, n, with_gather=True):
         if overlap:
             wc.step_pipelined(events=e)
         else:
-            if e: e[0].record(s_tick)
-            wc.tick()
-            if e: e[1].record(s_tick)
-            if e: e[2].record(s_tick)
-            wc.sim_step()
-            if e: e[3].record(s_tick)
+            if getattr(a, "closed_loop", False):   # one call: the tick reads the sim state, the sim takes tau
+                if e: e[0].record(s_tick)
+                wc.step()
+                if e: e[1].record(s_tick); e[2].record(s_tick); e[3].record(s_tick)   # (k_tick_ms = tick + sim of that call)
+            else:
+                if e: e[0].record(s_tick)
+                wc.tick()
+                if e: e[1].record(s_tick)
+                if e: e[2].record(s_tick)
+                wc.sim_step()
+                if e: e[3].record(s_tick)
         if gather is None:
             return
         if side_gather:
@@ -331,6 +347,8 @@ def workload_name(a, n):
         s = (f"cfg3: {n} OP3 LIPM walking per GPU (footstep plan along the demo path, LIPM/DCM CoM reference + swing "
              "trajectories -> update_tasks each tick; TSID tick + sim step")
         s += ", robot<->robot hull pairs collided)" if a.self_collision else ", floor contacts only)"
+        if getattr(a, "closed_loop", False):
+            s += "; LOOP CLOSED: the tick reads the sim state, the sim is driven by tau, touch-down feedback"
         if a.randomize:
             s += "; cfg5 randomised mass / friction / floor tilt + 1 cm terrain steps"
         if a.dephase > 0:
@@ -360,6 +378,7 @@ def secondary_runs(a, dev):
         ("cfg3_walk_4096_tight_torque_bounds", dict(workload="walk", tau_max_scaling=0.12, dephase=0.5, preroll=800), 4096),
         # the per-GPU share of the 4096 walkers at 8 GPUs (strong split): a step is one wavefront's latency (k_sim's);
         # capturing the steps in a HIP graph (one launch per 16 steps) does not help - the host is not the bound
+        ("cfg3_walk_4096_closed_loop", dict(workload="walk", closed_loop=True, steps=max(a.secondary_steps, 400), preroll=600), 4096),
         ("cfg3_walk_512_eager", dict(workload="walk", steps=800), 512),
         ("cfg3_walk_512_graph16", dict(workload="walk", steps=800, graph=16), 512),
     ]
