@@ -274,6 +274,7 @@ def run_workload(a, dev, rank, world, n, with_gather=True):
     loop_frac += (wc.info[:, 0] > 1).float().mean()
     ds_frac += (wc.contact_active.sum(dim=1) == 2).float().mean()
     failed_any.zero_(); loop_frac.zero_(); ds_frac.zero_()
+    wc.sync_sim()          # nothing of the warm-up is left for the timed region
     if world > 1 and with_gather:
         dist.barrier()
     torch.cuda.synchronize()
@@ -305,6 +306,7 @@ def run_workload(a, dev, rank, world, n, with_gather=True):
                 loop_frac += (wc.info[:, 0] > 1).float().mean()
                 ds_frac += (wc.contact_active.sum(dim=1) == 2).float().mean()
                 n_stat += 1
+    wc.sync_sim()          # (sim stages step_pipelined() has not enqueued yet belong to the timed steps)
     torch.cuda.synchronize()
     if world > 1 and with_gather:
         dist.barrier()

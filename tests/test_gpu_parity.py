@@ -622,9 +622,11 @@ def test_fallen_robot_hits_the_contact_cap(oracle):
     assert ncon_max == 32 and bool(torch.isfinite(wc.qpos).all())
 
 
-def test_step_pipelined_equals_step():
-    """sim(t) on a second stream overlapping tick(t+1): same results, bit for bit, as the serial step()."""
-    a, b = make(96, reference_quirks=False), make(96, reference_quirks=False)
+@pytest.mark.parametrize("batch", [1, 3])
+def test_step_pipelined_equals_step(batch):
+    """sim(t) on a second stream overlapping tick(t+1): same results, bit for bit, as the serial step() - also with the
+    sim stages enqueued several at a time (conf.pipeline_sim_batch; 25 steps leave one of them for sync_sim to flush)."""
+    a, b = make(96, reference_quirks=False), make(96, reference_quirks=False, pipeline_sim_batch=batch)
     perturb(a, 5); perturb(b, 5)
     for _ in range(25):
         a.step()

@@ -95,6 +95,7 @@ class WalkController:
         self.v_min = -self.v_max
         self.LF_frame, self.RF_frame = 0, 1
         self.t = 0.0
+        self.sim_batch = max(1, int(getattr(conf, "pipeline_sim_batch", 1)))   # step_pipelined(): sim stages enqueued this many at a time
         self.reset()
         self.q0 = self.q.clone()  # WalkController.py:23 (after the z shift of :74, which aliases q0)
 
@@ -234,32 +235,28 @@ class WalkController:
             raise _lib.TsidbError("step_pipelined needs the open-loop sim stage (closed loop: the tick reads the sim state)")
         cur = torch.cuda.current_stream(self.device)
         if getattr(self, "_pipe", None) is None:
-            self._pipe = dict(stream=torch.cuda.Stream(device=self.device), par=0, done=[None, None],
-                              q=[torch.empty_like(self.q), torch.empty_like(self.q)],
-                              v=[torch.empty_like(self.v), torch.empty_like(self.v)])
+            K = 2 * self.sim_batch
+            self._pipe = dict(stream=torch.cuda.Stream(device=self.device), par=0, done=[None] * K, pending=[],
+                              q=[torch.empty_like(self.q) for _ in range(K)], v=[torch.empty_like(self.v) for _ in range(K)])
         P = self._pipe
         par = P["par"]
-        P["par"] ^= 1
+        P["par"] = (par + 1) % len(P["q"])
         if events:
             events[0].record(cur)
         self.tick()
         if events:
             events[1].record(cur)
         if P["done"][par] is not None:
-            cur.wait_event(P["done"][par])     # the sim that read this slot two steps ago
+            cur.wait_event(P["done"][par])     # the sim that read this slot 2 * sim_batch steps ago
         P["q"][par].copy_(self.q)
         P["v"][par].copy_(self.v)
-        ready = torch.cuda.Event()
-        ready.record(cur)
-        with torch.cuda.stream(P["stream"]):
-            P["stream"].wait_event(ready)
-            if events:
-                events[2].record(P["stream"])
-            self.sim_step(q_tsid=P["q"][par], v_tsid=P["v"][par], _from_pipe=True)
-            if events:
-                events[3].record(P["stream"])
-            P["done"][par] = torch.cuda.Event()
-            P["done"][par].record(P["stream"])
+        P["pending"].append(par)
+        # conf.pipeline_sim_batch > 1 enqueues the sim stages that many at a time (one cross-stream wait and one record
+        # per batch instead of per step; the sim state then lags the tick by up to that many steps until sync_sim()).
+        # Measured on 4096 walkers (DESIGN.md section 5 "Streams"): 4 at a time +5 % in a touch-down window, -1 % on the
+        # phase average, 2 at a time -4 % - the default stays 1.
+        if len(P["pending"]) >= self.sim_batch or events:
+            self._flush_sims(events)
         self.t += self.conf.dt
         return self.tau, self.q, self.v, self.status, self.obs
 
@@ -296,7 +293,7 @@ class WalkController:
             getattr(self, k).copy_(v)
         self.t = t_keep
         self.t_device.fill_(self.t)
-        self._pipe["done"] = [None, None]   # no event from outside the capture may be waited on inside it
+        self._pipe["done"] = [None] * len(self._pipe["q"])   # no event from outside the capture may be waited on inside it
         self._pipe["par"] = 0
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
@@ -306,7 +303,7 @@ class WalkController:
                 self.step_pipelined()
                 self.t_device += dt
             self.sync_sim()                 # join the sim stream: the graph ends with every kernel done
-        self._pipe["done"] = [None, None]
+        self._pipe["done"] = [None] * len(self._pipe["q"])
         self.t = t_keep                     # the capture advanced the host clock without running anything
 
         outer = self
@@ -320,10 +317,34 @@ class WalkController:
 
         return _Graph()
 
+    def _flush_sims(self, events=None):
+        """enqueue the sim stages of the ticks step_pipelined() has run since the last flush (oldest first)"""
+        P = self._pipe
+        if not P["pending"]:
+            return
+        cur = torch.cuda.current_stream(self.device)
+        ready = torch.cuda.Event()
+        ready.record(cur)
+        with torch.cuda.stream(P["stream"]):
+            P["stream"].wait_event(ready)
+            for i, slot in enumerate(P["pending"]):
+                last = i == len(P["pending"]) - 1
+                if events and last:
+                    events[2].record(P["stream"])
+                self.sim_step(q_tsid=P["q"][slot], v_tsid=P["v"][slot], _from_pipe=True)
+                if events and last:
+                    events[3].record(P["stream"])
+            done = torch.cuda.Event()
+            done.record(P["stream"])
+        for slot in P["pending"]:
+            P["done"][slot] = done
+        P["pending"] = []
+
     def sync_sim(self):
-        """Make the current stream wait for the sim stages step_pipelined() left in flight."""
+        """Make the current stream wait for the sim stages step_pipelined() left in flight (or not yet enqueued)."""
         P = getattr(self, "_pipe", None)
         if P is not None:
+            self._flush_sims()
             torch.cuda.current_stream(self.device).wait_stream(P["stream"])
 
     def tick(self):
