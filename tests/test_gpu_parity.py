@@ -771,6 +771,39 @@ def test_walking_env_loop_matches_oracle_walk(oracle):
     assert mixed > 100 and int((wc.status != 0).sum()) == 0
 
 
+def test_wide_batch_walking_parity(oracle):
+    """the walking env loop against the oracle's on a WIDE batch: 1024 de-phased walkers (random start delays, so that
+    start phase, lift-offs, touch-downs and single support are all present at every tick) through 700 ticks - statuses,
+    contact flags and contact lists bit-exact on every env, states to the tolerances of the 12-env test"""
+    from oracle.oracle import WalkTables
+    from tsid_control_amd.walk_planner import WalkSchedule, op3_walking_posture
+    n = 1024
+    wc = make(n, walking=True, reference_quirks=False)
+    wc.posture_ref += torch.as_tensor(op3_walking_posture(), device=wc.device)
+    lf, rf = wc.frames[0, 0, 9:11].cpu().numpy(), wc.frames[0, 1, 9:11].cpu().numpy()
+    sched = WalkSchedule.from_demo_paths(n, wc.conf, wc.device, wc.dtype, seed=9, q0_feet=(lf, rf),
+                                         com0=wc.com_ref[0, :3].cpu().numpy(), t_start=0.4)
+    g = torch.Generator().manual_seed(21)
+    sched.set_phase_offsets(torch.rand(n, generator=g, dtype=torch.float64) * 0.9)
+    st = mirror(wc)
+    st["frames"] = wc.frames.cpu().numpy().copy()
+    tables = WalkTables(sched)
+    mixed = 0
+    for i in range(700):
+        t = i * wc.conf.dt
+        sched.apply(wc, t)
+        wc.step()
+        oracle.env_step_batch(wc.params, st, nthreads=16, walk=tables.at(t))
+        if i % 50 == 49 or i == 699:
+            ns = wc.contact_active.sum(dim=1)
+            mixed += int(ns.min() != ns.max())
+            assert np.array_equal(wc.status.cpu().numpy(), st["status"]), i
+            assert np.array_equal(wc.contact_active.cpu().numpy(), st["contact_active"]), i
+            assert np.array_equal(wc.ncon.cpu().numpy(), st["ncon"]) and np.array_equal(wc.con_pairs.cpu().numpy(), st["con_geom"]), i
+            assert diff(wc.tau, st["tau"]) < 1e-6 and diff(wc.q, st["q"]) < 1e-8 and diff(wc.qpos, st["qpos"]) < 1e-8, i
+    assert mixed >= 5 and int((wc.status != 0).sum()) == 0   # 50- and 38-variable QPs side by side in most of the checks
+
+
 def test_reward_and_done_outputs(oracle):
     """reward[N], done[N] (SURVEY.md 8d write list; no reference counterpart) ride in columns 65, 66 of the
     per-env row: tracking reward minus torque cost; done = failed QP / non-finite input / base too low / tilted."""
