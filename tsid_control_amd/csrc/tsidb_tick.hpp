@@ -1111,9 +1111,11 @@ __device__ __forceinline__ void tsid_tick_env(const DevModel<T> &m, TickLds<T> &
   const int n = c.n;
 
   // ---- task right-hand sides
-  if (lane < 2) se3_rhs(L, lane, contact_ref + 12 * lane, 12, m.params[P_KP_CONTACT], m.params[P_KD_CONTACT], L.k.arhs[lane]);
-  else if (lane < 4) se3_rhs(L, lane - 2, foot_ref + 24 * (lane - 2), 24, m.params[P_KP_FOOT], m.params[P_KD_FOOT], L.k.arhs[lane]);
-  else if (lane < 7) {
+  if (lane < 4) { // contact LF / RF, foot LF / RF: ONE copy of se3_rhs for the four lanes (two copies in two branches ran one after the other)
+    const bool ct = lane < 2;
+    se3_rhs(L, lane & 1, ct ? contact_ref + 12 * lane : foot_ref + 24 * (lane - 2), ct ? 12 : 24,
+            ct ? m.params[P_KP_CONTACT] : m.params[P_KP_FOOT], ct ? m.params[P_KD_CONTACT] : m.params[P_KD_FOOT], L.k.arhs[lane]);
+  } else if (lane < 7) {
     const int i = lane - 4;
     L.k.acomr[i] = -m.params[P_KP_COM] * (L.com[i] - com_ref[i]) - m.params[P_KD_COM] * (L.vcom[i] - com_ref[3 + i]) +
                  com_ref[6 + i] - L.acomd[i];
