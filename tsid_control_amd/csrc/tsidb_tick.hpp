@@ -1280,32 +1280,32 @@ __device__ __forceinline__ void tsid_tick_env(const DevModel<T> &m, TickLds<T> &
   __syncthreads();
   // ---- observations from this tick's data (main.py:132-142 reads data() before recomputing)
   if (obs) {
-    if (lane == 0) {
-      T fz[2], copw[2][3];
+    // contact wrenches in the sole frames: component i of foot fo on lane 6 fo + i (twelve 12-term sums side by side
+    // instead of one lane doing all 144 terms), then the small centre-of-pressure arithmetic on the broadcast values
+    T wl = 0;
+    if (lane < 12) {
+      const int fo = lane / 6, i = lane % 6;
 #pragma unroll
-      for (int fo = 0; fo < 2; fo++) {
-        T w[6] = {0, 0, 0, 0, 0, 0};
-        for (int e = 0; e < 12; e++) {
-          T fe = L.as.s[12 * fo + e];
-#pragma unroll
-          for (int i = 0; i < 6; i++) w[i] += m.Tgen[i][e] * fe;
-        }
-        T cl[3] = {0, 0, 0};
-        const bool on = fo == 0 ? act0 : act1;
-        if (on && w[2] > T(1e-3)) { cl[0] = w[4] / w[2]; cl[1] = w[3] / w[2]; }
-        const T *F = (m.params[P_QUIRKS] != 0 && cop_frames) ? cop_frames + 12 * fo : L.oMf[fo];
-#pragma unroll
-        for (int i = 0; i < 3; i++) copw[fo][i] = F[3 * i] * cl[0] + F[3 * i + 1] * cl[1] + F[3 * i + 2] * cl[2] + F[9 + i];
-        fz[fo] = w[2];
-      }
-      T cop[3] = {0, 0, 0};
-      if (act0 && act1 && fz[0] + fz[1] != 0) {
-        cop[0] = (copw[0][0] * fz[0] + copw[1][0] * fz[1]) / (fz[0] + fz[1]);
-        cop[1] = (copw[0][1] * fz[0] + copw[1][1] * fz[1]) / (fz[0] + fz[1]);
-      }
-#pragma unroll
-      for (int i = 0; i < 3; i++) obs[NQ + NV + 3 + i] = cop[i];
+      for (int e = 0; e < 12; e++) wl += m.Tgen[i][e] * L.as.s[12 * fo + e];
     }
+    T fz[2], copw[2][3];
+#pragma unroll
+    for (int fo = 0; fo < 2; fo++) {
+      const T w2 = rdlane(wl, 6 * fo + 2), w3 = rdlane(wl, 6 * fo + 3), w4 = rdlane(wl, 6 * fo + 4);
+      T cl[3] = {0, 0, 0};
+      const bool on = fo == 0 ? act0 : act1;
+      if (on && w2 > T(1e-3)) { cl[0] = w4 / w2; cl[1] = w3 / w2; }
+      const T *F = (m.params[P_QUIRKS] != 0 && cop_frames) ? cop_frames + 12 * fo : L.oMf[fo];
+#pragma unroll
+      for (int i = 0; i < 3; i++) copw[fo][i] = F[3 * i] * cl[0] + F[3 * i + 1] * cl[1] + F[3 * i + 2] * cl[2] + F[9 + i];
+      fz[fo] = w2;
+    }
+    T cop[3] = {0, 0, 0};
+    if (act0 && act1 && fz[0] + fz[1] != 0) {
+      cop[0] = (copw[0][0] * fz[0] + copw[1][0] * fz[1]) / (fz[0] + fz[1]);
+      cop[1] = (copw[0][1] * fz[0] + copw[1][1] * fz[1]) / (fz[0] + fz[1]);
+    }
+    if (lane < 3) obs[NQ + NV + 3 + lane] = lane == 0 ? cop[0] : (lane == 1 ? cop[1] : cop[2]);
     if (lane >= 8 && lane < 11) obs[NQ + NV + lane - 8] = L.com[lane - 8];
     if (lane >= 16 && lane < 19) obs[NQ + NV + 6 + lane - 16] = L.oMf[0][9 + lane - 16];
     if (lane >= 24 && lane < 27) obs[NQ + NV + 9 + lane - 24] = L.oMf[1][9 + lane - 24];
