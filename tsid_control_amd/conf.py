@@ -93,7 +93,8 @@ class RobotConfig:
     mask_am = (1.0, 1.0, 0.0)  #   (legacy/biped.py:83), zero reference (legacy/biped.py:86-87)
     qp_max_iter = 1000         # eiquadprog-fast DEFAULT_MAX_ITER
     hessian_regularization = 1e-8  # tsid SolverHQuadProgFast default
-    pipeline_sim_batch = 1     # WalkController.step_pipelined(): sim stages are enqueued on their stream this many at a time
+    pipeline_sim_batch = 0     # WalkController.step_pipelined(): sim stages enqueued on their stream this many at a time; 0 = auto
+                               # (4 for up to 1024 envs, else 1)
     self_collision = True      # sim stage collides the robot<->robot convex-hull pairs, as mj_step does (main.py:195);
     #                            False = floor contacts only (round-1 behaviour)
     w_cop = 0.0                # CoP force task of legacy/biped.py:79-80 (legacy/op3_conf.py:14 uses 0); 0 = off

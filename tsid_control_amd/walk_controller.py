@@ -95,7 +95,10 @@ class WalkController:
         self.v_min = -self.v_max
         self.LF_frame, self.RF_frame = 0, 1
         self.t = 0.0
-        self.sim_batch = max(1, int(getattr(conf, "pipeline_sim_batch", 1)))   # step_pipelined(): sim stages enqueued this many at a time
+        b = int(getattr(conf, "pipeline_sim_batch", 0))
+        # 0 = auto: small batches are latency bound, there the barrier packets of the per-step cross-stream handshake are
+        # 15-20 % of a step (measured: 512 envs +7 %, 1024 +5 %, 2048 and up nothing / noise)
+        self.sim_batch = b if b > 0 else (4 if self.num_envs <= 1024 else 1)   # step_pipelined(): sim stages enqueued this many at a time
         self.reset()
         self.q0 = self.q.clone()  # WalkController.py:23 (after the z shift of :74, which aliases q0)
 
@@ -253,8 +256,9 @@ class WalkController:
         P["pending"].append(par)
         # conf.pipeline_sim_batch > 1 enqueues the sim stages that many at a time (one cross-stream wait and one record
         # per batch instead of per step; the sim state then lags the tick by up to that many steps until sync_sim()).
-        # Measured on 4096 walkers (DESIGN.md section 5 "Streams"): 4 at a time +5 % in a touch-down window, -1 % on the
-        # phase average, 2 at a time -4 % - the default stays 1.
+        # Measured (DESIGN.md section 5 "Streams"): 4096 walkers, 4 at a time: +5 % in a touch-down window, -1 % on the
+        # phase average, 2 at a time -4 % - no batching there; 512 / 1024 walkers: +7 % / +5 % with 4 at a time (the default
+        # for up to 1024 envs).
         if len(P["pending"]) >= self.sim_batch or events:
             self._flush_sims(events)
         self.t += self.conf.dt
