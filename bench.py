@@ -364,11 +364,19 @@ def workload_name(a, n):
     return f"cfg2: {n} perturbed stand/balance per GPU"
 
 
+def kernel_words(wc):
+    """DESIGN.md section 4 "Algorithmic bytes", with the robot's dimensions (v1: 347 and 185 words per env per launch)"""
+    tick_words = (wc.NQ + wc.NV + 9 + wc.NA + 48 + 24 + 2) + (wc.NQ + wc.NV + wc.NA + wc.NV + 24 + 1 + wc.NOBS + 2)
+    sim_words = (wc.NQ + wc.NQ + 2 * wc.NV) + (wc.NQ + 2 * wc.NV)
+    return tick_words, sim_words
+
+
 def secondary_runs(a, dev):
     """The unfavourable paths beside the headline, each a short run of its own."""
     out = {}
     base = dict(dtype=a.dtype, randomize=False, dephase=0.0, tau_max_scaling=None, graph=0, steps=a.secondary_steps, warmup=20,
-                preroll=600, event_every=4, no_overlap=a.no_overlap, sync_gather=False, self_collision=a.self_collision)
+                preroll=600, event_every=4, no_overlap=a.no_overlap, sync_gather=False, self_collision=a.self_collision,
+                robot="v1", closed_loop=False)
     cases = [
         ("cfg2_stand_1024", dict(workload="stand", steps=max(a.secondary_steps, 400), warmup=200), 1024),
         ("cfg2_stand_4096", dict(workload="stand", steps=max(a.secondary_steps, 400), warmup=200), 4096),
@@ -383,14 +391,39 @@ def secondary_runs(a, dev):
         ("cfg3_walk_4096_closed_loop", dict(workload="walk", closed_loop=True, steps=max(a.secondary_steps, 400), preroll=600), 4096),
         ("cfg3_walk_512_eager", dict(workload="walk", steps=800), 512),
         ("cfg3_walk_512_graph16", dict(workload="walk", steps=800, graph=16), 512),
+        # the per-GPU shares of the 4096 walkers at 4 and 2 GPUs (strong split)
+        ("cfg3_walk_1024_eager", dict(workload="walk", steps=800), 1024),
+        ("cfg3_walk_2048_eager", dict(workload="walk", steps=600), 2048),
+        # BASELINE configs[4]: 65536 envs, randomised mass / friction / floor tilt + 1 cm terrain steps
+        ("cfg5_65536_randomized", dict(workload="walk", randomize=True, steps=max(a.secondary_steps // 2, 100), event_every=8), 65536),
+        # the reference's second robot (robot/v0: 52 collision meshes, condim 4, joint damping), perturbed standing
+        ("v0_stand_4096", dict(workload="stand", robot="v0", steps=max(a.secondary_steps, 200), warmup=100), 4096),
     ]
+    wsz = 8 if a.dtype == "f64" else 4
     for name, over, n in cases:
         b = SimpleNamespace(**{**base, **over})
         res, wc, _, _ = run_workload(b, dev, 0, 1, n, with_gather=False)
+        closed = bool(getattr(b, "closed_loop", False))
+        tick_ms = None if res["graph_steps"] else res["tick_ms"]
+        # closed loop: tick and sim are ONE call (tsidb_step) - the events bracket both, there is no separate sim time
+        sim_ms = None if (res["graph_steps"] or closed) else res["sim_ms"]
+        roof = None
+        if tick_ms is not None:
+            tw, sw = kernel_words(wc)
+            if b.randomize:
+                sw += 8 + 20
+            if closed:
+                dom, dms, words = "k_tick + k_sim (one tsidb_step call)", tick_ms, tw + sw
+            elif sim_ms >= tick_ms:
+                dom, dms, words = "k_sim", sim_ms, sw
+            else:
+                dom, dms, words = "k_tick", tick_ms, tw
+            ach = n * words * wsz / (dms * 1e-3) / 1e9
+            roof = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                    "algorithmic_bytes_per_launch": n * words * wsz, "avg_launch_ms": dms}
         out[name] = {"workload": workload_name(b, n), "value": n * b.steps / res["el"], "unit": "env-steps/s",
                      "steps": b.steps, "ms_per_step": 1e3 * res["el"] / b.steps,
-                     "k_tick_ms": None if res["graph_steps"] else res["tick_ms"],
-                     "k_sim_ms": None if res["graph_steps"] else res["sim_ms"],
+                     "k_tick_ms": tick_ms, "k_sim_ms": sim_ms, "roofline": roof,
                      "hip_graph_steps_per_launch": res["graph_steps"], "last_step_stats": res["stats"]}
         del wc
         torch.cuda.empty_cache()
@@ -428,9 +461,7 @@ def main():
         er, ewc, _, _ = run_workload(ea, dev, rank, world, n, with_gather=False)
         tick_ms, sim_ms = er["tick_ms"], er["sim_ms"]
         del ewc
-    # DESIGN.md section 4 "Algorithmic bytes", with the robot's dimensions (v1: 347 and 185 words)
-    tick_words = (wc.NQ + wc.NV + 9 + wc.NA + 48 + 24 + 2) + (wc.NQ + wc.NV + wc.NA + wc.NV + 24 + 1 + wc.NOBS + 2)
-    sim_words = (wc.NQ + wc.NQ + 2 * wc.NV) + (wc.NQ + 2 * wc.NV)
+    tick_words, sim_words = kernel_words(wc)
     assert args.robot != "v1" or (tick_words, sim_words) == (TICK_WORDS, SIM_WORDS)
     dom, dom_ms, dom_words = ("k_tick", tick_ms, tick_words) if tick_ms >= sim_ms else ("k_sim", sim_ms, sim_words)
     if args.randomize and dom == "k_sim":

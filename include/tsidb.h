@@ -133,8 +133,8 @@ int tsidb_step(tsidb_handle h, void *q, void *v, void *qpos, void *qvel, void *q
  * feedback (closed loop; td_latch [N] int32, initialised to -1, may be NULL = off): when the last sim step's contact
  * list (ncon, con_pairs of tsidb_sim / tsidb_step) shows the swing foot on the floor after td_fraction of its
  * swing, the touch-down is taken at once - the foot is a stance foot for the rest of that step.  t_device (may be
- * NULL): one value of the path's arithmetic type in device memory that replaces `t` - the launch can then be captured
- * in a HIP graph and replayed while the caller advances the clock on the device. */
+ * NULL): one float64 value (whatever the path's arithmetic type) in device memory that replaces `t` - the launch can
+ * then be captured in a HIP graph and replayed while the caller advances the clock on the device. */
 int tsidb_walk_update(tsidb_handle h, const void *coef, const int32_t *side, const int32_t *nsteps,
                       const void *rest, const void *com, int K, double t, double step_duration, double t_start,
                       double omega, double com_z0, double com_drop, const void *frames, const void *t_offset,
@@ -147,9 +147,10 @@ int tsidb_rbd_terms(tsidb_handle h, const void *q, const void *v, void *M, void 
                     void *oMf, void *com, void *stream);
 
 /* dimensions of the robot this library was built for (one library per robot: libtsidb.so = the v1 robot of ctrl/conf.py:9-15,
- * libtsidb_v0.so = robot/v0): out6 = NJ, NQ, NV, NA, sim bodies, 1 if the sim stage is built.  The TSIDB_N*
- * constants above are the v1 robot's. */
-int tsidb_dims(int *out6);
+ * libtsidb_v0.so = robot/v0): out9 = NJ, NQ, NV, NA, sim bodies, 1 if the sim stage is built, collision geoms, contact
+ * dimension, 1 if joints are damped - the nine ints of the blob's model_dims section, which tsidb_create compares.  The
+ * TSIDB_N* constants above are the v1 robot's. */
+int tsidb_dims(int *out9);
 
 /* bytes of LDS one env occupies in kernel `which` (0 tick, 1 sim) for `dtype` */
 int tsidb_lds_bytes(int dtype, int which);

@@ -115,6 +115,30 @@ static void chol_solve(double L[NV][NV], int n, const double *b, double *x) {
   }
 }
 
+/* rank-1 update (sigma = +1) or downdate (-1) of a lower Cholesky factor: L L^T <- L L^T + sigma x x^T (x is destroyed).
+ * Returns -1 when a downdate loses positive definiteness (the caller then rebuilds the factor). */
+static int chol_rank1(double L[NV][NV], int n, double *x, double sigma) {
+  for (int k = 0; k < n; k++) {
+    if (x[k] == 0.0) continue;
+    const double r2 = L[k][k] * L[k][k] + sigma * x[k] * x[k];
+    if (!(r2 > 0)) return -1;
+    const double r = sqrt(r2), c = r / L[k][k], s = x[k] / L[k][k];
+    L[k][k] = r;
+    for (int i = k + 1; i < n; i++) {
+      L[i][k] = (L[i][k] + sigma * s * x[i]) / c;
+      x[i] = c * x[i] - s * L[i][k];
+    }
+  }
+  return 0;
+}
+
+/* diagnostics (tools/newton_stats.py): rows whose state changed per Newton iteration after the first, all threads */
+int or_newton_incr_max = OR_NEWTON_INCR_MAX;
+long or_newton_hist[OR_MAXEFC + 2];
+void or_newton_hist_get(long *out, int reset) {
+  for (int i = 0; i < OR_MAXEFC + 2; i++) { out[i] = or_newton_hist[i]; if (reset) or_newton_hist[i] = 0; }
+}
+
 typedef struct {
   int nefc, ncon;
   double J[OR_MAXEFC][NV], aref[OR_MAXEFC], D[OR_MAXEFC], R[OR_MAXEFC], floss[OR_MAXEFC];
@@ -529,6 +553,12 @@ int or_sim_step_ext(const OrModel *m, double *qpos, double *qvel, const double *
     for (int i = 0; i < nefc; i++) jar[i] -= e.aref[i];
     double cost = 0;
     int iter = 0;
+    /* Newton Hessian H = M + J^T D J over the rows in their quadratic zone.  Built and factored in full on the first
+     * iteration; afterwards only the rows whose state changed are applied to the FACTOR as rank-1 updates / downdates
+     * with sqrt(D_i) J_i (what MuJoCo's Newton solver does for pyramidal cones: HessianIncremental / mju_cholUpdate),
+     * unless more than OR_NEWTON_INCR_MAX rows changed or a downdate loses definiteness - then it is rebuilt. */
+    double Hf[NV][NV];
+    int have_fac = 0, act_prev[OR_MAXEFC];
     for (;;) {
       /* update: constraint state, cost, gradient, Newton direction */
       double ccost = efc_update(&e, jar, force, active), gauss = 0;
@@ -548,18 +578,37 @@ int or_sim_step_ext(const OrModel *m, double *qpos, double *qvel, const double *
       }
       cost = newcost;
       if (iter >= maxiter) break;
-      double H[NV][NV];
-      memcpy(H, M, sizeof H);
-      for (int i = 0; i < nefc; i++) {
-        if (!active[i]) continue;
-        for (int a = 0; a < NV; a++) {
-          if (e.J[i][a] == 0) continue;
-          double da = e.D[i] * e.J[i][a];
-          for (int b2 = 0; b2 < NV; b2++) H[a][b2] += da * e.J[i][b2];
+      int need_full = !have_fac;
+      if (have_fac) {
+        int nchange = 0;
+        for (int i = 0; i < nefc; i++) nchange += active[i] != act_prev[i];
+        __atomic_fetch_add(&or_newton_hist[nchange], 1, __ATOMIC_RELAXED);
+        if (nchange > or_newton_incr_max) need_full = 1;
+        for (int i = 0; i < nefc && !need_full; i++) {
+          if (active[i] == act_prev[i]) continue;
+          double vec[NV];
+          const double sd = sqrt(e.D[i]);
+          for (int k = 0; k < NV; k++) vec[k] = sd * e.J[i][k];
+          if (chol_rank1(Hf, NV, vec, active[i] ? 1.0 : -1.0)) need_full = 1;
+          else info->newton_rank1++;
         }
       }
-      if (chol(H, NV)) return -2;
-      chol_solve(H, NV, grad, search);
+      if (need_full) {
+        memcpy(Hf, M, sizeof Hf);
+        for (int i = 0; i < nefc; i++) {
+          if (!active[i]) continue;
+          for (int a = 0; a < NV; a++) {
+            if (e.J[i][a] == 0) continue;
+            double da = e.D[i] * e.J[i][a];
+            for (int b2 = 0; b2 < NV; b2++) Hf[a][b2] += da * e.J[i][b2];
+          }
+        }
+        if (chol(Hf, NV)) return -2;
+        info->newton_full++;
+      }
+      have_fac = 1;
+      memcpy(act_prev, active, sizeof(int) * nefc);
+      chol_solve(Hf, NV, grad, search);
       for (int k = 0; k < NV; k++) search[k] = -search[k];
 
       /* exact line search */

@@ -519,7 +519,7 @@ int or_tsid_tick_cop(const OrModel *m, const double *params, double *q, double *
   static __thread OrTerms t;
   static __thread OrQP qp;
   static __thread OrQPSol sol;
-  { /* a non-finite state or reference never enters the solver: HQP_STATUS_ERROR, nothing touched */
+  { /* a non-finite state or reference never enters the solver: HQP_STATUS_ERROR, state untouched, outputs zeroed */
     double chk = 0;
     for (int i = 0; i < OR_NQ; i++) chk += fabs(q[i]);
     for (int i = 0; i < OR_NV; i++) chk += fabs(v[i]);
@@ -529,6 +529,9 @@ int or_tsid_tick_cop(const OrModel *m, const double *params, double *q, double *
     for (int i = 0; i < 24; i++) chk += fabs(contact_ref[i]);
     if (!(chk <= 1e300)) {
       if (iters) *iters = 0;
+      memset(tau, 0, OR_NA * sizeof(double)); /* as after a failed solve: nothing of an earlier tick is handed on */
+      memset(dv, 0, OR_NV * sizeof(double));
+      memset(f, 0, 24 * sizeof(double));
       or_last_rowx[0] = 0.0; or_last_rowx[1] = 1.0;
       return 4;
     }

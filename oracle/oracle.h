@@ -31,6 +31,9 @@ enum { OR_NJ = 21, OR_NQ = 27, OR_NV = 26, OR_NA = 20, OR_NB = 21, OR_NF = 2, OR
 #endif
 enum { OR_NVAR = OR_NV + 24, OR_NEQ = 18, OR_NIN = 68 + 2 * OR_NA + 2 * OR_NV };
 enum { OR_NROWC = 2 * (OR_CONDIM - 1) /* pyramid rows per contact */ };
+enum { OR_NEWTON_INCR_MAX = 8 /* Newton: at most this many changed rows are applied to the factor as rank-1 updates;
+                                 more, and the Hessian is rebuilt and factored (same constant in csrc/tsidb_sim.hpp) */ };
+extern int or_newton_incr_max;  /* run-time copy (diagnostics may change it) */
 enum { OR_MAXCON = 32, OR_MAXHH = 12 /* robot<->robot contacts per env */, OR_MAXEFC = OR_NA + OR_NROWC * OR_MAXCON,
        OR_NOBS = OR_NQ + OR_NV + 12 };
 int or_dims(int *out6); /* NJ, NQ, NV, NA, sim bodies, has_sim of this build */
@@ -153,6 +156,7 @@ typedef struct {
   double con_frame[OR_MAXCON][3]; /* contact normal (geom1 -> geom2), world */
   int flags;                      /* bit 3 (8): a penetrating robot<->robot pair was dropped (contact caps) */
   int con_body2[OR_MAXCON];      /* body of geom2 */
+  int newton_full, newton_rank1; /* Newton Hessian factorisations from scratch / rows applied as rank-1 updates */
 } OrSimInfo;
 int or_sim_step(const OrModel *m, double *qpos, double *qvel, const double *ctrl, double *qacc_ws,
                 OrSimInfo *info);

@@ -41,7 +41,7 @@ def _structs(NQ, NV, NA, condim=3):
                     ("efc_force", C.c_double * MAXEFC), ("qacc", C.c_double * NV), ("qacc_smooth", C.c_double * NV),
                     ("qfrc_bias", C.c_double * NV), ("qfrc_actuator", C.c_double * NV), ("M", C.c_double * (NV * NV)),
                     ("con_body1", C.c_int * MAXCON), ("con_frame", C.c_double * (3 * MAXCON)), ("flags", C.c_int),
-                    ("con_body2", C.c_int * MAXCON)]
+                    ("con_body2", C.c_int * MAXCON), ("newton_full", C.c_int), ("newton_rank1", C.c_int)]
 
     import types
     return types.SimpleNamespace(OrTerms=OrTerms, OrQP=OrQP, OrQPSol=OrQPSol, OrSimInfo=OrSimInfo, NQ=NQ, NV=NV, NA=NA,

@@ -107,6 +107,7 @@ def test_v0_library_exports_and_rejects_the_other_robot(v0):
     L0 = _lib.load_for(v0["blob"]["model_dims"])
     L1 = _lib.load_for(ModelBlob()["model_dims"])
     assert _lib.dims(L0) == (19, 25, 24, 18, 19, 1) and _lib.dims(L1) == (21, 27, 26, 20, 21, 1)
+    assert _lib.dims9(L0)[6:] == (52, 4, 1) and _lib.dims9(L1)[6:] == (21, 3, 0)   # geoms, contact dimension, damping
     p = np.zeros(P_COUNT)
     h = ctypes.c_void_p()
     raw = ModelBlob().raw                        # the v1 blob handed to the v0 build: refused before any HIP call

@@ -1,0 +1,27 @@
+"""f32 path against the float64 oracle from identical inputs: one tick's wrench per component, one env step's state, contact pairs
+(what BASELINE.md section 5 asks of the f32 path)."""
+import sys, numpy as np, torch
+sys.path.insert(0, "."); sys.path.insert(0, "tests")
+import test_gpu_parity as T
+from oracle.oracle import Oracle
+from tsid_control_amd.model import ModelBlob
+orc = Oracle(ModelBlob().raw)
+n = 256
+wc = T.make(n, "f32"); T.perturb(wc, 4); st = T.mirror(wc)
+wc.step()
+orc.env_step_batch(wc.params, st, nthreads=8)
+w, w0 = T.wrench(wc.f.double().cpu().numpy(), wc.params), T.wrench(st["f"], wc.params)
+d = np.abs(w - w0)
+print("wrench err per component (max over envs, feet):", d.max(axis=(0, 1)))
+print("wrench |ref| per component (max):", np.abs(w0).max(axis=(0, 1)))
+print("worst ratio err / (1e-4 + 1e-3 |ref|) per component:", (d / (1e-4 + 1e-3 * np.abs(w0))).max(axis=(0, 1)))
+fz = np.abs(w0[:, :, 2])
+print("moment err / (fz * 1 m):", (d[:, :, 3:] / fz[:, :, None]).max(axis=(0, 1)), " force err / fz:", (d[:, :, :3] / fz[:, :, None]).max(axis=(0, 1)))
+for k in ("tau", "dv", "q", "v", "qpos", "qvel"):
+    a = getattr(wc, k).double().cpu().numpy(); b = st[k].reshape(a.shape)
+    print(f"{k:5s} max abs err {np.abs(a - b).max():.3e}   max |ref| {np.abs(b).max():.3e}")
+same = (wc.con_pairs.cpu().numpy() == st["con_geom"]).all(axis=1)
+print("contact pair lists equal:", int(same.sum()), "of", n, "; ncon equal:", int((wc.ncon.cpu().numpy() == st["ncon"]).sum()))
+bad = np.where(~same)[0][:5]
+for e in bad:
+    print(" env", e, "gpu", wc.con_pairs[e, :10].tolist(), "cpu", st["con_geom"][e, :10].tolist())

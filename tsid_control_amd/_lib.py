@@ -19,22 +19,28 @@ class TsidbError(RuntimeError):
     pass
 
 
-def dims(L):
-    """(NJ, NQ, NV, NA, sim bodies, has_sim) of the robot a loaded library was built for"""
-    out = (C.c_int * 6)()
+def dims9(L):
+    """the nine ints a library was built for, in the order of the blob's model_dims section:
+    NJ, NQ, NV, NA, sim bodies, has_sim, collision geoms, contact dimension, damped joints"""
+    out = (C.c_int * 9)()
     L.tsidb_dims(out)
     return tuple(out)
+
+
+def dims(L):
+    """(NJ, NQ, NV, NA, sim bodies, has_sim) of the robot a loaded library was built for"""
+    return dims9(L)[:6]
 
 
 def load_for(model_dims):
     """The library built for a blob's robot (its model_dims section): one libtsidb*.so per robot sits next to this file
     (libtsidb.so = the v1 robot, libtsidb_v0.so = robot/v0).  TSIDB_LIB_PATH (diagnostic builds) is tried first."""
-    want = tuple(int(x) for x in model_dims)[:6]   # (the blob's further entries - geoms, condim, damping - are checked by tsidb_create)
+    want = tuple(int(x) for x in model_dims)[:9]   # all nine: two builds may differ in geoms / condim / damping only
     cands = [LIB_PATH] + sorted(p for p in _HERE.glob("libtsidb*.so") if p != LIB_PATH)
     for p in cands:
         if p.exists():
             L = load(p)
-            if dims(L) == want:
+            if dims9(L)[:len(want)] == want:
                 return L
     raise TsidbError(f"no libtsidb*.so in {_HERE} is built for a robot with dimensions {want}: compile the blob's topology "
                      "header into a library (python -c 'import __graft_entry__ as g; g.build()')")

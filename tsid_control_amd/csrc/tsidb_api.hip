@@ -45,6 +45,11 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2))) void 
     if (lane < 48) chk += fabs(foot_ref[E * 48 + lane]);
     if (lane < 24) chk += fabs(contact_ref[E * 24 + lane]);
     if (__ballot(!(chk <= Eps<T>::inf))) {
+      // nothing of an earlier tick is handed on either: tau = dv = f = 0, as after a failed solve (in the closed loop
+      // the env's motors go limp instead of being driven by stale torques)
+      if (lane < NA) tau[E * NA + lane] = 0;
+      if (lane < NV) dv[E * NV + lane] = 0;
+      if (lane < 24) f[E * 24 + lane] = 0;
       if (lane == 0) {
         status[e] = 4;
         if (info) { info[E * 4] = 0; info[E * 4 + 1] = 0; }
@@ -187,7 +192,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void k_walk(int n, const T *coef, const int *side, const int *nsteps, const T *rest, const T *com,
                                               int K, T t_now, const T *t_off, T Tstep, T t_start, T omega, T z0, T dz, const T *frames, T *foot_ref,
                                               T *contact_ref, uint8_t *cact, T *com_ref, const int *ncon, const int *con, int *latch,
-                                              unsigned long long fgeoms0, unsigned long long fgeoms1, T td_frac, const T *t_dev) {
+                                              unsigned long long fgeoms0, unsigned long long fgeoms1, T td_frac, const double *t_dev) {
   // 16 lanes per env: every lane evaluates the (cheap) polynomials, each writes its share of the rows, so
   // the table reads hit one line per env and the reference rows are written as contiguous runs
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -195,7 +200,8 @@ __global__ __launch_bounds__(256) void k_walk(int n, const T *coef, const int *s
   if (e >= n) return;
   const size_t E = (size_t)e;
   // per-env start delay (de-phased schedules): the env's own clock starts at t_off[e]
-  T t = t_dev ? t_dev[0] : t_now; // device clock: a captured graph replays with the time it finds there
+  T t = t_dev ? (T)t_dev[0] : t_now; // device clock (always float64: a float32 clock advanced by dt per tick drifts by
+                                     // ~one dt over a few thousand ticks): a captured graph replays with the time it finds there
   if (t_off) { t -= t_off[e]; t = t > 0 ? t : T(0); }
   // timeline: [0, t_start) both feet down; step k in [t_start + k T, t_start + (k+1) T); then the final stand
   const int k = t < t_start ? -1 : (int)floor((t - t_start) / Tstep);
@@ -572,6 +578,32 @@ static void build_model(tsidb_ctx *h, DevModel<T> &m) {
   m.hull_edge = h->d_edge;
 }
 
+// The kernels index the hull arrays with addresses taken from the blob and pack (geom << 16 | vertex) with bit 15 as
+// the robot<->robot flag: check every address table against the section it indexes before anything is uploaded
+// (Blob::validate only knows section bounds).
+static void validate_geometry(const Blob &b) {
+  if constexpr (!TOPO_HAS_SIM) return;
+  const int *ha = b.i32("mj_hull_adr", NG + 1), *ca = b.i32("mj_chunk_adr", NG + 1);
+  const int64_t nvert = b.count("mj_hull_vert") / 3, nchunk = b.count("mj_chunk_box") / 6, nedge = b.count("mj_hull_edge");
+  if (b.count("mj_hull_vert") % 3 || b.count("mj_chunk_box") % 6) throw std::string("model blob: hull vertex / chunk box sections are not whole records");
+  if (ha[0] != 0 || ha[NG] != nvert || ca[0] != 0 || ca[NG] != nchunk) throw std::string("model blob: hull / chunk address tables do not span their sections");
+  for (int g = 0; g < NG; g++) {
+    const int64_t nv = (int64_t)ha[g + 1] - ha[g], nc = (int64_t)ca[g + 1] - ca[g];
+    if (nv < 1 || nc < 1) throw std::string("model blob: hull or chunk addresses are not increasing");
+    if (nv >= 0x8000) throw std::string("model blob: a hull has 32768 or more vertices (contact ids keep the vertex in 15 bits)");
+    if (nc > WAVE || nc * WAVE < nv) throw std::string("model blob: a hull's chunks do not cover it (at most 64 chunks of 64 vertices)");
+  }
+  if ((int64_t)b.count("mj_hull_eadr") != nvert + 1) throw std::string("model blob: hull graph address table has the wrong length");
+  const int *ea = b.i32("mj_hull_eadr", 0), *ed = b.i32("mj_hull_edge", 0);
+  if (ea[0] != 0 || ea[nvert] > nedge) throw std::string("model blob: hull graph addresses exceed the edge list");
+  for (int g = 0; g < NG; g++)
+    for (int v = ha[g]; v < ha[g + 1]; v++) {
+      if (ea[v + 1] < ea[v]) throw std::string("model blob: hull graph addresses are not increasing");
+      for (int e = ea[v]; e < ea[v + 1]; e++)
+        if (ed[e] < 0 || ed[e] >= ha[g + 1] - ha[g]) throw std::string("model blob: hull graph edge leaves its hull");
+    }
+}
+
 template <typename T>
 static void upload_model(tsidb_ctx *h) {
   const Blob &b = h->blob;
@@ -681,6 +713,7 @@ int tsidb_create(const void *model_blob, size_t nbytes, const double *params, in
     HIP_OK(hipGetDeviceCount(&ndev));
     if (device < 0 || device >= ndev) throw std::string("no such HIP device (this library has no CPU path)");
     HIP_OK(hipSetDevice(device));
+    validate_geometry(h->blob);
     if (dtype == TSIDB_F64) upload_model<double>(h); else upload_model<float>(h);
     if (TOPO_HAS_SIM) { // sim body of each sole frame: frame -> TSID joint -> sim joint (mj_sim2tsid) -> body
       const int *fp = h->blob.i32("pin_frame_parent", 2), *s2t = h->blob.i32("mj_sim2tsid", NA);
@@ -827,7 +860,7 @@ int tsidb_walk_update(tsidb_handle h, const void *coef, const int32_t *side, con
                        (const float *)rest, (const float *)com, K, (float)t, (const float *)t_offset, (float)step_duration, (float)t_start, (float)omega,
                        (float)com_z0, (float)com_drop, (const float *)frames, (float *)h->foot_ref, (float *)h->contact_ref,
                        (uint8_t *)h->contact_active, (float *)h->com_ref, ncon, con_pairs, td_latch, h->foot_geoms[0], h->foot_geoms[1],
-                       (float)td_fraction, (const float *)t_device);
+                       (float)td_fraction, (const double *)t_device);
   HIP_OK(hipGetLastError());
   GUARD_END
 }
@@ -855,11 +888,12 @@ int tsidb_debug_stamps(unsigned long long *out, int n) {
 }
 #endif
 
-/* dimensions of the robot this library was built for: NJ, NQ, NV, NA, NB (sim bodies), 1 if the sim stage is built */
-int tsidb_dims(int *out6) {
-  if (!out6) return -1;
-  const int d[6] = {NJ, NQ, NV, NA, NB, TOPO_HAS_SIM}; // (the blob's model_dims also carries NG, condim, damping)
-  for (int i = 0; i < 6; i++) out6[i] = d[i];
+/* dimensions of the robot this library was built for, in the order of the blob's model_dims section: NJ, NQ, NV, NA,
+ * NB (sim bodies), 1 if the sim stage is built, NG (collision geoms), contact dimension, 1 if joints are damped */
+int tsidb_dims(int *out9) {
+  if (!out9) return -1;
+  const int d[9] = {NJ, NQ, NV, NA, NB, TOPO_HAS_SIM, NG, CONDIM, TOPO_EULERDAMP};
+  for (int i = 0; i < 9; i++) out9[i] = d[i];
   return 0;
 }
 

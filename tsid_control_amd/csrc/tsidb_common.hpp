@@ -275,6 +275,16 @@ template <typename T> __device__ __forceinline__ T subtree_sum32(T v, int last) 
   return (bperm(p, last) - p) + v;
 }
 
+__device__ __forceinline__ int wave_sum_int(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, true);
+  return __builtin_amdgcn_readlane(v, 63);
+}
+
 template <int CTRL, int ROW_MASK, typename T> __device__ __forceinline__ T dpp_min_step(T v) {
   // lanes a disabled row would leave at 0 must not win the min: feed the lane's own value instead
   T w;

@@ -18,6 +18,11 @@
 namespace tsidb {
 
 constexpr int LDM = 27;
+#ifndef TSIDB_NEWTON_INCR_MAX
+#define TSIDB_NEWTON_INCR_MAX 8
+#endif
+constexpr int NEWTON_INCR_MAX = TSIDB_NEWTON_INCR_MAX; // Newton: at most this many changed rows are applied to the factor as
+                                                       // rank-1 updates; more, and the Hessian is rebuilt (< 0: never incremental)
 
 // floor plane n.x = d with its contact frame (mju_makeFrame: t1 from y unless |n_y| >= 0.5, t2 = n x t1)
 template <typename T>
@@ -158,6 +163,113 @@ __device__ __forceinline__ T chol26_solve(T (&a)[NV], T rhs, int lane, bool &spd
 // inlined next to the sparse one it doubles the Newton loop's code for nothing
 template <typename T>
 __device__ __noinline__ T chol26_dense(T (&a)[NV], T rhs, int lane, bool &spd) { return chol26_solve<T, true>(a, rhs, lane, spd); }
+
+// The same factorisation in three pieces, for the Newton loop, which keeps the factor from one iteration to the next:
+//   chol26_factor  A = U U^T (tree-sparse, as above); 1 / U[k][k] ends up in lane k of rdv (a VGPR: 26 wave-uniform
+//                  reciprocals are 52 SGPRs)
+//   chol26_subst   x = A^-1 rhs from the factor
+//   chol26_rank1   U U^T <- U U^T + sigma x x^T for a vector x supported on ONE root path of the tree (a constraint row's
+//                  Jacobian: the dofs of the contact body's ancestors) - pivots outside the path are untouched, and the
+//                  path's own pairs are all ancestor pairs, so the update stays inside the sparsity pattern.  Returns
+//                  false when a downdate (sigma = -1) loses positive definiteness; the caller then rebuilds the factor.
+template <typename T>
+__device__ __forceinline__ void chol26_factor(T (&a)[NV], T &rdv, int lane, bool &spd) {
+  int ln = lane;
+  asm volatile("" : "+v"(ln));
+  int notspd = 0;
+  rdv = 0;
+#pragma unroll
+  for (int t = 0; t < NV; t++) {
+    const int k = NV - 1 - t;
+    const T akk = rdlane(a[k], k);
+    notspd = akk > 0 ? notspd : 1;
+    asm volatile("" : "+v"(notspd));
+    const T rk = rsqrt_t(akk > 0 ? akk : T(1));
+    rdv = ln == k ? rk : rdv;
+    T uik = ln < k ? a[k] * rk : (ln == k ? akk * rk : T(0));
+    a[k] = uik;
+    int jl = -1; // (broadcasts four at a time, read ahead of their FMAs: see chol26_solve)
+#pragma unroll
+    for (int j0 = 0; j0 < k; j0 += 4) {
+      const bool p0 = (MJ_DOFANC[k] >> j0) & 1u, p1 = j0 + 1 < k && ((MJ_DOFANC[k] >> (j0 + 1)) & 1u),
+                 p2 = j0 + 2 < k && ((MJ_DOFANC[k] >> (j0 + 2)) & 1u), p3 = j0 + 3 < k && ((MJ_DOFANC[k] >> (j0 + 3)) & 1u);
+      if (!(p0 || p1 || p2 || p3)) continue;
+      const T u0 = p0 ? rdlane(uik, j0) : T(0), u1 = p1 ? rdlane(uik, j0 + 1) : T(0), u2 = p2 ? rdlane(uik, j0 + 2) : T(0),
+              u3 = p3 ? rdlane(uik, j0 + 3) : T(0);
+      if (jl >= 0) asm volatile("" : "+v"(uik), "+v"(a[jl]) : "s"(u0), "s"(u1), "s"(u2), "s"(u3));
+      else asm volatile("" : "+v"(uik) : "s"(u0), "s"(u1), "s"(u2), "s"(u3));
+      if (p0) { a[j0] -= uik * u0; jl = j0; }
+      if (p1) { a[j0 + 1] -= uik * u1; jl = j0 + 1; }
+      if (p2) { a[j0 + 2] -= uik * u2; jl = j0 + 2; }
+      if (p3) { a[j0 + 3] -= uik * u3; jl = j0 + 3; }
+    }
+  }
+  spd = notspd == 0;
+#pragma unroll
+  for (int k = 0; k < NV; k++) asm volatile("" : "+v"(a[k]));
+}
+
+// x = A^-1 rhs from the factor A = U U^T: `a` = row `lane` of U in registers, `Up` = the same factor parked in LDS (row stride
+// LDM).  Both substitutions are column-oriented - one broadcast and one FMA per pivot, all lanes at once:
+//   U y = rhs     descendants first: y_k = acc_k / U_kk, then acc_i -= U[i][k] y_k on every lane i (U[i][k] = a[k])
+//   U^T x = y     ancestors first:   x_i = acc_i / U_ii, then acc_k -= U[i][k] x_i on every lane k - which needs COLUMN k
+//                 of U on lane k: read back transposed from the parked copy (26 conflict-free ds_read_b64 per lane;
+//                 entries below the diagonal are exact zeros).
+// (The first version ran the second pass row-oriented from `a` alone: a dot product across lanes per pivot, i.e. two
+//  v_readlane + one FMA per ancestor PAIR - 780 instructions against 160.)
+template <typename T>
+__device__ __forceinline__ T chol26_subst(const T (&a)[NV], const T *Up, T rdv, T rhs, int lane) {
+  int ln = lane;
+  asm volatile("" : "+v"(ln));
+  T b[NV];
+#pragma unroll
+  for (int i = 0; i < NV; i++) b[i] = lane < NV ? Up[i * LDM + lane] : T(0);
+  T acc = rhs, yv = 0;
+#pragma unroll
+  for (int t = 0; t < NV; t++) {
+    const int k = NV - 1 - t;
+    const T yl = acc * rdv;
+    const T yk = rdlane(yl, k);
+    yv = ln == k ? yl : yv;
+    acc -= a[k] * yk;
+  }
+  acc = yv;
+  T x = 0;
+#pragma unroll
+  for (int i = 0; i < NV; i++) {
+    const T xl = acc * rdv;
+    const T xi = rdlane(xl, i);
+    x = ln == i ? xl : x;
+    acc -= b[i] * xi;
+  }
+  return x;
+}
+
+template <typename T>
+__device__ __forceinline__ bool chol26_rank1(T (&a)[NV], T &rdv, T xv, T sigma, unsigned long long chain, int lane) {
+  // per pivot k on the path, with s = x_k / U_kk and c = sqrt(1 + sigma s^2) (the diagonal's growth factor):
+  //   lanes i <= k: U[i][k] <- (U[i][k] + sigma s x_i) / c   (at i = k this is U_kk c, the new diagonal)
+  //                 x_i     <- c x_i - s U[i][k]             (0 at i = k)
+  // lanes > k hold zeros in both (x there was consumed by the earlier pivots, U is upper triangular)
+  bool ok = true;
+#pragma unroll
+  for (int t = 0; t < NV; t++) {
+    const int k = NV - 1 - t;
+    if (ok && ((chain >> k) & 1ull)) { // (wave-uniform)
+      const T s = rdlane(xv * rdv, k);
+      const T q = T(1) + sigma * s * s;
+      if (!(q > (sizeof(T) == 8 ? T(1e-10) : T(1e-5)))) ok = false; // downdate to (nearly) singular: rebuild instead
+      else {
+        const T ic = rsqrt_t(q), c = q * ic;
+        const T un = (a[k] + sigma * s * xv) * ic;
+        xv = lane == k ? T(0) : c * xv - s * un;
+        a[k] = un;
+        rdv = lane == k ? rdv * ic : rdv;
+      }
+    }
+  }
+  return ok;
+}
 
 // out = M * x for the lane's dof (x in LDS)
 template <typename T> __device__ __forceinline__ T mulM(const SimLds<T> &L, const T *x, int lane) {
@@ -600,6 +712,96 @@ __device__ __forceinline__ bool boxes_may_touch(const DevModel<T> &m, const SimL
 }
 
 template <typename T> __device__ __forceinline__ unsigned bodyanc_of(const DevModel<T> &m, int b) { return m.mj_anc[b]; }
+
+// The linear algebra of one Newton iteration, out of line:  search direction = H^-1 grad  from the LDS copy of H.
+//   mode 0  L.H holds a freshly assembled Hessian: factor it (tree-sparse U U^T) and park the factor in its place
+//           (column 26: 1 / diagonal);
+//   mode 1  L.H holds the factor parked by an earlier iteration: apply the constraint rows whose state changed since
+//           (bits of `chg`: bit 0 = this lane's friction row, bit 1 + i = row i of this lane's contact; `actbits` = the new
+//           states) as rank-1 updates (row entered its quadratic zone) / downdates (left it) with sqrt(D_r) J_r, park it
+//           again.  The row's Jacobian is not materialised elsewhere either: entry k = S_k,lin . dir + S_k,ang . (r x dir
+//           [+ torsional part]) with the sign of the body chain dof k is on.
+// then the two substitutions.  status: 0 = fine, 1 = the Hessian is not positive definite, 2 = a downdate lost
+// definiteness (the caller assembles the Hessian and comes back with mode 0).
+// Out of line on purpose: inlined, the factor's 26 rows and the row construction are register-allocated together with
+// the Newton loop, and the kernel - at the 256-VGPR limit of two wavefronts per SIMD - spilled two dozen loop-carried
+// values to scratch, which cost more than the row updates saved (measured: line search +40 %, every phase +5 %).
+template <typename T> struct NewtonDir { T search; int status; };
+template <typename T>
+__device__ __noinline__ NewtonDir<T> newton_direction(const DevModel<T> &m, SimLds<T> &L, int nfl, int mode, unsigned chg, unsigned actbits,
+                                                      T mu, T cD, T fD, T grad) {
+  const int lane = threadIdx.x;
+  NewtonDir<T> out;
+  out.search = 0;
+  out.status = 0;
+  T arow[NV], rdv = 0;
+#pragma unroll
+  for (int j = 0; j < NV; j++) arow[j] = lane < NV ? L.H[lane * LDM + j] : T(0);
+  bool store = true;
+  if (mode == 0) {
+    bool spd;
+    chol26_factor<T>(arow, rdv, lane, spd);
+    if (!spd) { out.status = 1; return out; }
+  } else {
+    rdv = lane < NV ? L.H[lane * LDM + NV] : T(0);
+    store = __ballot(chg != 0) != 0ull;
+    while (true) {
+      const unsigned long long mk = __ballot(chg != 0);
+      if (!mk) break;
+      const int src = __ffsll((long long)mk) - 1;
+      const unsigned bits = (unsigned)__builtin_amdgcn_readlane((int)chg, src);
+      const int bit = __ffs(bits) - 1;
+      if (lane == src) chg &= ~(1u << bit);
+      const T sigma = (((unsigned)__builtin_amdgcn_readlane((int)actbits, src) >> bit) & 1u) ? T(1) : T(-1);
+      const int bk = lane < 6 ? 0 : lane - 5; // body of this lane's dof
+      T xv = 0;
+      unsigned pathm; // bodies on the root path that carries the row's Jacobian
+      if (bit == 0) { // friction row of dof `src`: sqrt(D) e_src
+        const T d = rdlane_dyn(fD, src);
+        xv = lane == src ? d * rsqrt_t(d) : T(0);
+        pathm = L.anc[src < 6 ? 0 : src - 5];
+        if (lane > src) pathm = 0;
+      } else { // row bit - 1 of contact `src`
+        const int c = src, i = bit - 1;
+        T cn[3], ct1[3], ct2[3];
+        const int b1 = contact_frame(L, c, nfl, cn, ct1, ct2);
+        const T muc = rdlane_dyn(mu, c), d = rdlane_dyn(cD, c);
+        const T sg = i >= 4 ? T(0) : ((i & 1) ? -muc : muc);
+        const T *tk = i < 2 ? ct1 : ct2;
+        const T dl[3] = {cn[0] + sg * tk[0], cn[1] + sg * tk[1], cn[2] + sg * tk[2]};
+        T rxd[3];
+        cross3(L.cr[c], dl, rxd);
+        if constexpr (CONDIM > 3) {
+          if (i >= 4) {
+            const T mt = (i & 1) ? -m.contact[9] : m.contact[9];
+            rxd[0] += mt * cn[0]; rxd[1] += mt * cn[1]; rxd[2] += mt * cn[2];
+          }
+        }
+        const unsigned m2 = L.anc[L.cbody[c]], m1 = b1 >= 0 ? L.anc[b1] : 0u;
+        pathm = m2 | m1;
+        if (lane < NV) {
+          const int sgn = (int)((m2 >> bk) & 1u) - (int)((m1 >> bk) & 1u);
+          if (sgn != 0) {
+            const T *Sk = L.S[lane];
+            const T jv = Sk[0] * dl[0] + Sk[1] * dl[1] + Sk[2] * dl[2] + Sk[3] * rxd[0] + Sk[4] * rxd[1] + Sk[5] * rxd[2];
+            const T sd = d * rsqrt_t(d);
+            xv = sgn > 0 ? sd * jv : -(sd * jv);
+          }
+        }
+      }
+      const unsigned long long chain = __ballot(lane < NV && ((pathm >> bk) & 1u));
+      if (!chol26_rank1<T>(arow, rdv, xv, sigma, chain, lane)) { out.status = 2; return out; }
+    }
+  }
+  if (store && lane < NV) {
+#pragma unroll
+    for (int j = 0; j < NV; j++) L.H[lane * LDM + j] = arow[j];
+    L.H[lane * LDM + NV] = rdv;
+  }
+  __syncthreads(); // (one wavefront: orders the parked rows before the transposed read)
+  out.search = chol26_subst<T>(arow, L.H, rdv, grad, lane);
+  return out;
+}
 
 // per-lane constraint bookkeeping (friction row of dof `lane`, contact `lane`)
 template <typename T>
@@ -1115,6 +1317,14 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
     const T scale = T(1) / (m.meaninertia * NV);
     T cost = 0;
     int iter = 0;
+    // Newton Hessian H = M + J^T D J over the rows in their quadratic zone: built and factored in full on the first
+    // iteration; afterwards only the rows whose state changed are applied to the FACTOR, as rank-1 updates / downdates
+    // with sqrt(D_r) J_r (MuJoCo's Newton solver does the same for pyramidal cones: HessianIncremental, mju_cholUpdate) -
+    // unless more than NEWTON_INCR_MAX rows changed, a downdate loses definiteness, or a robot<->robot contact couples
+    // two branches of the tree (dense factor).  In a touch-down window 80 % of the later iterations change <= 2 rows
+    // (tools/newton_stats.py).  Between iterations the factor is parked in the LDS copy of H (column 26: 1 / diagonal).
+    bool have_fac = false;
+    unsigned prevbits = 0; // bit 0: this lane's friction row was in its quadratic zone, bit 1 + i: contact row i was active
     TSIDB_LAP_ZERO(24); TSIDB_LAP_ZERO(25); TSIDB_LAP_ZERO(26); TSIDB_LAP_ZERO(27); TSIDB_LAP_ZERO(28);
     TSIDB_LAP_INIT();
     while (true) {
@@ -1193,6 +1403,27 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
       cost = newcost;
       if (iter >= maxiter) break;
       TSIDB_LAP(24);
+      unsigned actbits = fact ? 1u : 0u;
+      if (rs.has_c) {
+#pragma unroll
+        for (int i = 0; i < NROWC; i++) actbits |= rs.cjar[i] < 0 ? (2u << i) : 0u;
+      }
+      bool full = NEWTON_INCR_MAX < 0 || !have_fac || hh_cross;
+      bool ok = true;
+      T search = 0;
+      if (!full) {
+        unsigned chg = actbits ^ prevbits;
+        int nchange = __popc(chg);
+        nchange = wave_sum_int(nchange);
+        if (nchange > NEWTON_INCR_MAX) full = true;
+        else {
+          const NewtonDir<T> nd = newton_direction<T>(m, L, nfl, 1, chg, actbits, mu, rs.cD, rs.fD, grad);
+          search = -nd.search;
+          if (nd.status != 0) full = true; // a downdate lost definiteness: rebuild
+        }
+      }
+      prevbits = actbits;
+      if (full) {
       // ---- Newton Hessian H = M + J^T D J: CRB recursion on the per-body contact inertia
       if (rs.has_c) {
         // W = [A, -A [r]x ; [r]x A, -[r]x A [r]x] with [r]x the cross matrix of the contact point
@@ -1320,18 +1551,18 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
         __syncthreads();
       }
       TSIDB_LAP(25);
-#pragma unroll
-      for (int j = 0; j < NV; j++) arow[j] = lane < NV ? L.H[lane * LDM + j] : T(0);
-      bool ok;
-      T search;
-      if (hh_cross) { // rare: the out-of-line dense variant works on a copy, so that `arow` itself never leaves the registers
+      if (hh_cross) { // rare: the dense variant (out of line as well)
         T dense_rows[NV];
 #pragma unroll
-        for (int j = 0; j < NV; j++) dense_rows[j] = arow[j];
+        for (int j = 0; j < NV; j++) dense_rows[j] = lane < NV ? L.H[lane * LDM + j] : T(0);
         search = -chol26_dense(dense_rows, grad, lane, ok);
       } else {
-        search = -chol26_solve<T, false>(arow, grad, lane, ok);
+        const NewtonDir<T> nd = newton_direction<T>(m, L, nfl, 0, 0u, actbits, mu, rs.cD, rs.fD, grad);
+        search = -nd.search;
+        ok = nd.status == 0;
+        have_fac = true;
       }
+      } // (full)
       if (!ok) { fail |= 2; break; }
       TSIDB_LAP(26);
       // ---- exact line search along `search`

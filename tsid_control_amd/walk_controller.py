@@ -124,6 +124,7 @@ class WalkController:
 
     def set_params(self):
         """Re-read self.conf (edited RobotConfig values) into the device-side constants."""
+        self.sync_sim()  # sim stages step_pipelined() has not launched yet belong to the OLD constants: run them first
         self.params = pack_params(self.conf, self.model.effort_limit, self.model.velocity_limit)
         rc = self._L.tsidb_set_params(self._h, self.params.ctypes.data_as(C.c_void_p), P_COUNT)
         _lib.check(self._L, self._h, rc, "tsidb_set_params")
@@ -232,8 +233,12 @@ class WalkController:
         TSID, main.py:119-129 vs :192-195), so sim(t) and tick(t+1) are independent; the TSID state is
         handed to the sim through a two-slot snapshot.  tau, q, v, status, obs are valid on the current
         stream as after step(); the sim state (qpos, qvel, qacc_warmstart, ncon, con_pairs, info[:, 2:4])
-        is valid after sync_sim().  `events` = four torch.cuda.Event recorded around the tick (current
-        stream) and around the sim (sim stream), for timing."""
+        is valid after sync_sim() ONLY: with conf.pipeline_sim_batch > 1 (the default for up to 1024 envs is 4) the
+        last few sim stages are not even launched until the batch is full, so a device / stream synchronize does
+        not make the sim state current - sync_sim() launches them and makes the current stream wait.  Every entry
+        point of this class that reads or rewrites sim-side data (step, sim_step, reset, set_params, set_env_params,
+        capture_steps, WalkSchedule.apply with touch-down feedback) calls it.  `events` = four torch.cuda.Event
+        recorded around the tick (current stream) and around the sim (sim stream), for timing."""
         if getattr(self.conf, "closed_loop", False) or not getattr(self.conf, "sim_enabled", True):
             raise _lib.TsidbError("step_pipelined needs the open-loop sim stage (closed loop: the tick reads the sim state)")
         cur = torch.cuda.current_stream(self.device)
@@ -281,11 +286,12 @@ class WalkController:
             raise _lib.TsidbError("capture_steps uses the open-loop pipeline (step_pipelined)")
         dt = self.conf.dt
         self.sync_sim()   # the state saved below must include the sim stage a previous step_pipelined() left in flight
-        self.t_device = torch.full((1,), self.t, dtype=self.dtype, device=self.device)
+        self.t_device = torch.full((1,), self.t, dtype=torch.float64, device=self.device)   # float64 whatever the path's dtype
         # warm up outside the capture (lazy kernel loads, cached contiguous tables), then rewind the state
         keep = {k: getattr(self, k).clone() for k in ("q", "v", "qpos", "qvel", "qacc_warmstart", "com_ref", "posture_ref",
                                                       "foot_ref", "contact_ref", "contact_active", "frames", "rows", "tau", "dv", "f",
-                                                      "status", "ncon", "con_pairs", "info")}
+                                                      "status", "ncon", "con_pairs", "info", "cop_ref")}
+        latch_keep = sched.td_latch.clone() if sched is not None and sched.td_latch is not None else None
         t_keep = self.t
         if sched is not None:
             sched.apply(self, self.t, t_device=self.t_device)
@@ -295,6 +301,8 @@ class WalkController:
         torch.cuda.synchronize(self.device)
         for k, v in keep.items():
             getattr(self, k).copy_(v)
+        if latch_keep is not None:
+            sched.td_latch.copy_(latch_keep)
         self.t = t_keep
         self.t_device.fill_(self.t)
         self._pipe["done"] = [None] * len(self._pipe["q"])   # no event from outside the capture may be waited on inside it
@@ -317,7 +325,8 @@ class WalkController:
 
             def replay(self_inner):
                 g.replay()
-                outer.t += n_steps * dt
+                for _ in range(n_steps):   # the same additions the device clock and step_pipelined() make
+                    outer.t += dt
 
         return _Graph()
 

@@ -285,7 +285,7 @@ class WalkSchedule:
         """Device path of one tick's reference update: foot samples, contact switching and the CoM
         reference for every env in one kernel (tsidb_walk_update); equivalent to
         wc.update_tasks(*self.sample(t)) followed by wc.com_ref[:] = self.com_ref(t).  t_device: a one-element
-        tensor of the path's dtype holding the time - read by the kernel instead of `t` (graph capture)."""
+        float64 tensor holding the time - read by the kernel instead of `t` (graph capture)."""
         import ctypes as C
         from . import _lib
         if not hasattr(self, "_side32"):
@@ -293,6 +293,8 @@ class WalkSchedule:
             self._nsteps32 = self.nsteps.to(torch.int32).contiguous()
             self._coef_c, self._rest_c, self._com_c = self.coef.contiguous(), self.rest.contiguous(), self.com.contiguous()
         p = lambda x: C.c_void_p(x.data_ptr())
+        if self.td_latch is not None:
+            wc.sync_sim()  # the kernel reads the last sim step's contact list: nothing of it may still be in flight
         with torch.cuda.device(wc.device):
             rc = wc._L.tsidb_walk_update(wc._h, p(self._coef_c), p(self._side32), p(self._nsteps32), p(self._rest_c),
                                          p(self._com_c), self.K, float(t), float(self.conf.step_duration),
