@@ -141,6 +141,42 @@ int tsidb_walk_update(tsidb_handle h, const void *coef, const int32_t *side, con
                       const int32_t *ncon, const int32_t *con_pairs, int32_t *td_latch, double td_fraction,
                       const void *t_device, void *stream);
 
+/* ---- episode lifecycle on the device (SURVEY.md 8f-2, section 5 "auto-reset mask"; no reference counterpart: the reference
+ * runs one episode and exits, main.py:113-124) */
+
+/* tsidb_reset for exactly the envs whose done flag is set: rows [N, rows_ld >= TSIDB_NROW] as tsidb_tick wrote them
+ * (done in column TSIDB_NOBS + 1) - no host round trip between `done` and the restart.  frames (may be NULL) [N,2,12]
+ * receives the reset envs' sole placements (what the next tsidb_walk_update re-references contacts at). */
+int tsidb_reset_done(tsidb_handle h, const void *rows, int rows_ld, void *q, void *v, void *qpos, void *qvel, void *qacc_ws,
+                     void *frames, void *stream);
+
+/* [NA] values (the path's arithmetic type, device) added to the posture reference every reset captures
+ * (ctrl/WalkController.py:164-165 takes q0's joints; a walking workload keeps its knees bent).  NULL = none.  The pointer
+ * is remembered, not copied. */
+int tsidb_set_posture_bias(tsidb_handle h, const void *posture_bias);
+
+/* Episode plan for the selected envs, built on the device: env_ids (device int32, NULL = all) and / or done_rows (as for
+ * tsidb_reset_done: only envs whose done flag is set).  For each: footsteps along its path (ctrl/Footstep_Planner.py:92-125),
+ * swing polynomials from footstep k to k + 2 (ctrl/Walk_Planner.py:23-31, ctrl/Foot_Trajectory.py:5-27), rest placements and
+ * the LIPM / DCM CoM plan (ctrl/LIPM.py:34-49 in closed form) - the tables tsidb_walk_update reads (layouts there), starting
+ * from the sole placements and the CoM that tsidb_reset left in the registered cop_frames / com_ref buffers.
+ * plan_params [TSIDB_PLAN_NPARAMS] (host): step_length, step_width, step_height, step_duration, rise_ratio
+ * (ctrl/conf.py:24-28), t_start, com_drop, foot_press (every swing is aimed this far below the floor), resample_ds (path
+ * vertices at most this far apart before planning; 0 = as given), unicycle path v, w, dt, n (Footstep_Planner.py:131-141),
+ * scale_lo, scale_hi, seed.  Path per env: `path` [N,P,2] float64 + npts [N] = an explicit polyline in world coordinates,
+ * used as given; NULL = the unicycle path scaled by scale[e] ([N] float64) or, with scale NULL and episode [N] int32 given,
+ * by U(scale_lo, scale_hi) drawn from hash(seed, env, episode[e]) (bump_episode != 0 increments episode[e] first), rotated
+ * into the robot's heading and started between its feet.  Outputs: steps [N,K+2,4] float64 = x, y, yaw, side of every
+ * footstep (the two initial ones first); nsteps [N]; coef, side, rest, com as tsidb_walk_update reads them; flags [N] (may
+ * be NULL) bit 0 = the plan needed more than K steps and was cut.  The env's clock restarts: t_offset [N] (may be NULL)
+ * receives `t` (or *t_device, float64 device), td_latch [N] (may be NULL) -1. */
+enum { TSIDB_PLAN_NPARAMS = 16 };
+int tsidb_walk_plan(tsidb_handle h, const int32_t *env_ids, int n_ids, const void *done_rows, int rows_ld,
+                    const double *plan_params, int n_plan_params, const double *path, const int32_t *npts, int P,
+                    const double *scale, int32_t *episode, int bump_episode, int K, double *steps, void *coef, int32_t *side,
+                    int32_t *nsteps, void *rest, void *com, int32_t *flags, void *t_offset, int32_t *td_latch, double t,
+                    const double *t_device, void *stream);
+
 /* probe of formulation.computeProblemData's rigid-body terms (main.py:119): M [N,26,26],
  * hbias [N,26], Jcom [N,3,26], Jf [N,2,6,26] (LOCAL), oMf [N,2,12], com [N,3].  Test/debug use. */
 int tsidb_rbd_terms(tsidb_handle h, const void *q, const void *v, void *M, void *hbias, void *Jcom, void *Jf,

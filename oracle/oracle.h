@@ -205,6 +205,13 @@ void or_walk_update_fb(int n, const double *coef, const int32_t *side, const int
                        int32_t *latch, uint64_t fgeoms0, uint64_t fgeoms1 /* geoms of the left / right foot body */,
                        double td_frac);
 
+/* episode plan (or_walk.c): footsteps, swing polynomials, rest placements and the LIPM / DCM CoM plan per env - the twin of
+ * the device kernel behind tsidb_walk_plan; layouts in or_walk.c */
+void or_walk_plan(int n, const double *pp, const double *cop_frames, const double *com_ref, const double *path,
+                  const int32_t *npts, int P, const double *scale, const int32_t *episode, int K, double *steps_out,
+                  double *coef, int32_t *side, int32_t *nsteps, double *rest, double *com, int32_t *flags);
+uint64_t or_plan_hash(uint64_t seed, uint64_t env, uint64_t episode);
+
 /* walking tables for or_env_step_batch_walk (env-major, layouts as or_walk_update) */
 typedef struct {
   const double *coef, *rest, *com, *t_off;

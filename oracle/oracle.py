@@ -282,6 +282,29 @@ def walk_update(lib, sched, t, frames, foot_ref, contact_ref, contact_active, co
                        _p(contact_active), _p(com_ref))
 
 
+def walk_plan(lib, pp, cop_frames, com_ref, K, path=None, npts=None, scale=None, episode=None):
+    """or_walk_plan: the episode plan tables for n envs (layouts in or_walk.c).  pp = the 16 plan parameters
+    (tsid_control_amd.walk_planner.plan_params)."""
+    cop_frames, com_ref, pp = _f64(cop_frames), _f64(com_ref), _f64(pp)
+    n = cop_frames.shape[0]
+    P = 0
+    if path is not None:
+        path = _f64(path)
+        P = path.shape[1]
+        npts = np.ascontiguousarray(npts, dtype=np.int32)
+    scale = _f64(scale) if scale is not None else None
+    episode = np.ascontiguousarray(episode, dtype=np.int32) if episode is not None else None
+    out = dict(steps=np.zeros((n, K + 2, 4)), coef=np.zeros((n, K, 4, 4)), side=np.zeros((n, K), dtype=np.int32),
+               nsteps=np.zeros(n, dtype=np.int32), rest=np.zeros((n, K + 1, 2, 4)), com=np.zeros((n, K + 2, 2, 3)),
+               flags=np.zeros(n, dtype=np.int32))
+    o = lambda x: _p(x) if x is not None else None
+    lib.or_walk_plan.restype = None
+    lib.or_walk_plan.argtypes = [C.c_int] + [C.c_void_p] * 5 + [C.c_int, C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 7
+    lib.or_walk_plan(n, _p(pp), _p(cop_frames), _p(com_ref), o(path), o(npts), P, o(scale), o(episode), K, _p(out["steps"]),
+                     _p(out["coef"]), _p(out["side"]), _p(out["nsteps"]), _p(out["rest"]), _p(out["com"]), _p(out["flags"]))
+    return out
+
+
 def new_state(n, dims=None):
     """Zeroed env-major float64 state/IO arrays in the layout or_env_step_batch expects (dims = (NQ, NV, NA) of the
     robot; default the v1 robot's)."""

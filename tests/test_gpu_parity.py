@@ -1188,3 +1188,117 @@ def test_captured_graph_equals_eager_steps(dtype, replays):
               "foot_ref", "com_ref"):
         assert torch.equal(getattr(a, k), getattr(b, k)), k
     assert int((b.contact_active.sum(dim=1) == 1).sum()) > 0
+
+
+# ---------------------------------------------------------------------------- episode lifecycle on the device (f-2)
+def _walker(n, dtype="f64", seed=5, plan=True, **kw):
+    from tsid_control_amd.walk_planner import WalkSchedule, op3_walking_posture
+    wc = make(n, dtype, walking=True, reference_quirks=False)
+    wc.set_posture_bias(op3_walking_posture())
+    return wc, WalkSchedule.on_device(wc, seed=seed, plan=plan, **kw)
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_plan_kernel_matches_restatement_and_reference_footsteps(oracle, dtype):
+    """tsidb_walk_plan (k_plan) against oracle/or_walk.c:or_walk_plan - the unicycle path with drawn scales, every table -
+    and, through explicit polylines, against the reference's own footsteps (tests/golden/planners.json: PINNED)."""
+    import json
+    from pathlib import Path
+    from oracle.oracle import walk_plan
+    from tsid_control_amd.walk_planner import WalkSchedule, plan_params
+    tol = 1e-12 if dtype == "f64" else 2e-6
+    n = 48
+    wc, sched = _walker(n, dtype, seed=9, scale_range=(0.5, 0.97))
+    torch.cuda.synchronize()
+    ref = walk_plan(oracle.lib, sched.pp, wc.cop_frames.double().cpu().numpy(), wc.com_ref.double().cpu().numpy(), sched.K,
+                    episode=np.zeros(n, np.int32))
+    assert np.array_equal(sched.nsteps.cpu().numpy(), ref["nsteps"]) and int(sched.flags.sum()) == 0 and len(set(ref["nsteps"].tolist())) > 4
+    assert np.array_equal(sched.side.cpu().numpy(), ref["side"])
+    assert diff(sched.steps, ref["steps"]) < 1e-12          # footsteps are float64 whatever the path's type
+    for k in ("coef", "rest", "com"):
+        assert diff(getattr(sched, k), ref[k]) < tol, k
+    # golden footsteps through the device kernel: explicit paths, feet where the reference's demo puts them
+    gold = json.loads((Path(__file__).parent / "golden" / "planners.json").read_text())["footsteps"]
+    P = max(len(c["path"]) for c in gold)
+    path, npts = np.zeros((n, P, 2)), np.full(n, 2, np.int32)
+    path[:, 1, 0] = 1.0
+    for i, c in enumerate(gold):
+        path[i, :len(c["path"])], npts[i] = np.array(c["path"]), len(c["path"])
+    wc.cop_frames[:, 0, 9:11] = torch.tensor([0.0, 0.1], dtype=wc.dtype, device=wc.device)
+    wc.cop_frames[:, 1, 9:11] = torch.tensor([0.0, -0.1], dtype=wc.dtype, device=wc.device)
+    for i, c in enumerate(gold):
+        wc.conf.step_length, wc.conf.step_width = c["params"]["step_length"], c["params"]["step_width"]
+        sched.pp = plan_params(wc.conf, resample_ds=0.0)
+        sched.plan(wc, env_ids=[i], path=path, npts=npts)
+        want = np.array([[s["pos"][0], s["pos"][1], s["yaw"], int(s["side"])] for s in c["steps"]])
+        assert int(sched.nsteps[i]) + 2 == len(want)
+        assert diff(sched.steps[i, :len(want)], want) < (1e-12 if dtype == "f64" else 1e-7)   # (f32: the feet positions are read as float32)
+
+
+def test_episode_lifecycle_on_the_device():
+    """64 walkers; some are made to fall at chosen ticks (base pushed below done_base_height): the tick reports done,
+    reset_done() resets exactly those envs and replans them with a NEW path on the device (no host sync), and each then walks
+    again - bit for bit like a fresh controller whose schedule starts at that tick with that episode's path.  Envs that never
+    fell are bit-identical to a run without any reset."""
+    n, F = 64, 640
+    dt = 0.002
+    falls = {3: 150, 17: 150, 40: 420, 41: 420, 63: 420, 8: 421}
+    A, sa = _walker(n)
+    for i in range(F):
+        sa.apply(A, i * dt)
+        for e, r in falls.items():
+            if r == i:
+                A.q[e, 2] = 0.05
+        A.step()
+        if i in falls.values():
+            assert sorted(torch.nonzero(A.done).flatten().tolist()) == sorted(e for e, r in falls.items() if r == i)
+        A.reset_done(sa, t=(i + 1) * dt, new_paths=True)
+    torch.cuda.synchronize()
+    ep = sa.episode.cpu().numpy()
+    assert sorted(np.nonzero(ep)[0].tolist()) == sorted(falls) and ep.max() == 1 and int(A.done.sum()) == 0
+    assert float(A.q[:, 2].min()) > 0.25                     # everybody is up and walking
+    keys = ("q", "v", "tau", "dv", "f", "qpos", "qvel", "qacc_warmstart", "rows", "contact_active", "foot_ref", "com_ref", "contact_ref")
+    # never fell: identical to a run that never resets anything
+    C_, sc = _walker(n)
+    for i in range(F):
+        sc.apply(C_, i * dt)
+        C_.step()
+    stay = [e for e in range(n) if e not in falls]
+    for k in keys:
+        assert torch.equal(getattr(A, k)[stay], getattr(C_, k)[stay]), k
+    assert torch.equal(sa.coef[stay], sc.coef[stay]) and not torch.equal(sa.coef[3], sc.coef[3])   # the fallen ones got new paths
+    # fell at tick r: identical to a fresh controller started at tick r + 1 on episode 1's path
+    for r in sorted(set(falls.values())):
+        B, sb = _walker(n, plan=False)
+        sb.episode[:] = 1
+        sb.plan(B, t=(r + 1) * dt)
+        for i in range(r + 1, F):
+            sb.apply(B, i * dt)
+            B.step()
+        es = [e for e, rr in falls.items() if rr == r]
+        for k in keys:
+            assert torch.equal(getattr(A, k)[es], getattr(B, k)[es]), (k, r)
+        assert torch.equal(sa.coef[es], sb.coef[es]) and torch.equal(sa.com[es], sb.com[es])
+
+
+def test_reset_with_schedule_restarts_the_walk():
+    """WalkController.reset(env_ids, sched=...): the host-initiated form - the listed envs get their standing state back, their
+    plan rebuilt (same path unless new_paths) and their clock restarted; afterwards they repeat the batch's first ticks"""
+    n, dt = 16, 0.002
+    A, sa = _walker(n, seed=2)
+    first = {}
+    for i in range(300):
+        sa.apply(A, i * dt)
+        A.step()
+        if i < 100:
+            first[i] = (A.q[5].clone(), A.tau[5].clone(), A.qpos[5].clone())
+    A.reset(env_ids=[5, 9], sched=sa, t=300 * dt)
+    assert int(sa.episode[5]) == 0
+    for i in range(300, 400):
+        sa.apply(A, i * dt)
+        A.step()
+        q, tau, qpos = first[i - 300]
+        # (env time = i dt - 300 dt is not bit-equal to (i - 300) dt: compare to rounding, not bit for bit)
+        assert float((A.q[5] - q).abs().max()) < 1e-9 and float((A.tau[5] - tau).abs().max()) < 1e-6 and float((A.qpos[5] - qpos).abs().max()) < 1e-8
+    A.reset(env_ids=[9], sched=sa, t=400 * dt, new_paths=True)
+    assert int(sa.episode[9]) == 1 and int(sa.episode[5]) == 0

@@ -1,0 +1,92 @@
+"""Episode plan: the C restatement oracle/or_walk.c:or_walk_plan - the twin of the device kernel
+behind tsidb_walk_plan - against the reference's own footsteps (tests/golden/planners.json, PINNED) and against the
+host-side tables WalkSchedule.__init__ builds with numpy.  CPU only; the device kernel is checked against these in
+tests/test_gpu_parity.py."""
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from oracle.oracle import walk_plan
+from tsid_control_amd.conf import RobotConfig
+from tsid_control_amd.footstep_planner import Footstep, FootstepPlanner, resample_path, unicycle_path
+from tsid_control_amd.walk_planner import WalkSchedule, op3_walking_conf, plan_params
+
+GOLD = json.loads((Path(__file__).parent / "golden" / "planners.json").read_text())
+# path scales whose resampled pieces do not add up to exactly one step length (see WalkSchedule.on_device)
+SCALES = np.array([0.513, 0.587, 0.649, 0.707, 0.7713, 0.8391, 0.9077, 0.9931, 0.55, 0.61, 0.83, 0.97])
+LF, RF = np.array([0.035, 0.0]), np.array([-0.035, 0.0])
+
+
+def standing(n, lf=LF, rf=RF, com_z=0.24):
+    fr = np.zeros((n, 2, 12))
+    fr[:, 0, 9:11], fr[:, 1, 9:11] = lf, rf
+    cr = np.zeros((n, 9))
+    cr[:, :2], cr[:, 2] = 0.5 * (lf + rf), com_z
+    return fr, cr
+
+
+def host_schedule(conf, scales, **kw):
+    heading = float(np.arctan2(-(LF - RF)[0], (LF - RF)[1]))
+    ch, sh = np.cos(heading), np.sin(heading)
+    Rh = np.array([[ch, -sh], [sh, ch]])
+    plans = []
+    for sc in scales:
+        path = resample_path([Rh @ p + 0.5 * (LF + RF) for p in unicycle_path(scale=float(sc))], conf.step_length / 10)
+        plans.append(FootstepPlanner(conf.step_width, conf.step_length).plan(
+            path, [Footstep(LF, np.array([0, 0, heading]), 0), Footstep(RF, np.array([0, 0, heading]), 1)]))
+    return WalkSchedule(plans, conf, "cpu", torch.float64, com0=np.array([0.0, 0.0, 0.24]), heading=heading, **kw), plans
+
+
+@pytest.mark.parametrize("case", range(len(GOLD["footsteps"])))
+def test_plan_restatement_reproduces_the_reference_footsteps(oracle, case):
+    c = GOLD["footsteps"][case]
+    conf = RobotConfig()
+    conf.step_length, conf.step_width = c["params"]["step_length"], c["params"]["step_width"]
+    path = np.array(c["path"])[None]
+    fr, cr = standing(1, np.array([0.0, 0.1]), np.array([0.0, -0.1]))
+    out = walk_plan(oracle.lib, plan_params(conf, resample_ds=0.0), fr, cr, 40, path=path, npts=[path.shape[1]])
+    ref = np.array([[s["pos"][0], s["pos"][1], s["yaw"], int(s["side"])] for s in c["steps"]])
+    assert out["nsteps"][0] + 2 == len(ref) and out["flags"][0] == 0
+    assert np.abs(out["steps"][0, :len(ref)] - ref).max() < 1e-12
+    # capacity: a plan that does not fit is cut and flagged, never written past its rows
+    Ks = len(ref) - 3   # one step short
+    small = walk_plan(oracle.lib, plan_params(conf, resample_ds=0.0), fr, cr, Ks, path=path, npts=[path.shape[1]])
+    assert small["nsteps"][0] == Ks and small["flags"][0] == 1 and np.abs(small["steps"][0] - ref[:Ks + 2]).max() < 1e-12
+
+
+@pytest.mark.parametrize("rise_ratio,foot_press", [(0.5, 0.002), (0.3, 0.0)])
+def test_plan_restatement_matches_the_host_tables(oracle, rise_ratio, foot_press):
+    conf = op3_walking_conf(RobotConfig())
+    conf.rise_ratio = rise_ratio
+    sched, plans = host_schedule(conf, SCALES, foot_press=foot_press, t_start=0.7, com_drop=0.01)
+    fr, cr = standing(len(SCALES))
+    pp = plan_params(conf, t_start=0.7, com_drop=0.01, foot_press=foot_press)
+    out = walk_plan(oracle.lib, pp, fr, cr, sched.K, scale=SCALES)
+    assert np.array_equal(out["nsteps"], sched.nsteps.numpy()) and not out["flags"].any()
+    assert np.array_equal(out["side"], sched.side.numpy())
+    for e, st in enumerate(plans):
+        ref = np.array([[s.position[0], s.position[1], s.orientation[2], int(bool(s.side))] for s in st])
+        assert np.abs(out["steps"][e, :len(ref)] - ref).max() < 1e-12
+    for k in ("coef", "rest", "com"):
+        assert np.abs(out[k] - getattr(sched, k).numpy()).max() < 1e-11, k
+    assert abs(np.sqrt(9.80665 / (0.24 - 0.01)) - sched.omega) < 1e-15
+
+
+def test_plan_path_scale_draws(oracle):
+    """hash(seed, env, episode) -> U(lo, hi): deterministic, inside the range, different per env and per episode"""
+    conf = op3_walking_conf(RobotConfig())
+    fr, cr = standing(16)
+    pp = plan_params(conf, scale_range=(0.6, 0.9), seed=11)
+    a = walk_plan(oracle.lib, pp, fr, cr, 110, episode=np.zeros(16, np.int32))
+    b = walk_plan(oracle.lib, pp, fr, cr, 110, episode=np.zeros(16, np.int32))
+    c = walk_plan(oracle.lib, pp, fr, cr, 110, episode=np.ones(16, np.int32))
+    assert np.array_equal(a["steps"], b["steps"]) and not a["flags"].any()
+    # path length ~ 5 m x scale, one step per 5 cm: the step counts reveal the scales
+    assert a["nsteps"].min() >= 0.6 * 95 and a["nsteps"].max() <= 0.9 * 105 and len(set(a["nsteps"].tolist())) > 4
+    assert (a["nsteps"] != c["nsteps"]).sum() > 8
+    oracle.lib.or_plan_hash.restype = __import__("ctypes").c_uint64
+    oracle.lib.or_plan_hash.argtypes = [__import__("ctypes").c_uint64] * 3
+    assert oracle.lib.or_plan_hash(11, 3, 0) != oracle.lib.or_plan_hash(11, 3, 1) != oracle.lib.or_plan_hash(11, 4, 1)

@@ -25,3 +25,23 @@ print("contact pair lists equal:", int(same.sum()), "of", n, "; ncon equal:", in
 bad = np.where(~same)[0][:5]
 for e in bad:
     print(" env", e, "gpu", wc.con_pairs[e, :10].tolist(), "cpu", st["con_geom"][e, :10].tolist())
+# ---- per-env verdicts against BASELINE.md section 5 (rtol 1e-3 / atol 1e-4 for tau, dv, wrench; atol 1e-5 for the next state)
+def frac(name, a, b, rtol, atol):
+    a = a.reshape(n, -1); b = b.reshape(n, -1)
+    okenv = (np.abs(a - b) <= atol + rtol * np.abs(b)).all(axis=1)
+    print(f"{name:7s} envs within rtol {rtol:g} / atol {atol:g}: {int(okenv.sum())} of {n}; worst ratio {(np.abs(a - b) / (atol + rtol * np.abs(b))).max():.2f}")
+    return okenv
+g = lambda k: getattr(wc, k).double().cpu().numpy()
+frac("tau", g("tau"), st["tau"], 1e-3, 1e-4)
+frac("dv", g("dv"), st["dv"], 1e-3, 1e-4)
+frac("wrench", w, w0, 1e-3, 1e-4)
+# wrench error relative to the foot's normal force (the scale of the problem: the split of a wrench among 4 corner forces is fixed
+# only by the 1e-8 regularisation, so the conditioning argument is about |f|, not about each component)
+fzz = np.maximum(np.abs(w0[:, :, 2:3]), 1.0)
+print("wrench err / max(fz, 1 N): max", (np.abs(w - w0) / fzz).max())
+for k in ("q", "v"):
+    frac(k, g(k), st[k], 0.0, 1e-5)
+sub = same
+for k in ("qpos", "qvel"):
+    a, b = g(k)[sub], st[k].reshape(n, -1)[sub]
+    print(f"{k:5s} on the {int(sub.sum())} envs with identical contact lists: max abs err {np.abs(a - b).max():.3e}; within 1e-5: {int((np.abs(a - b) <= 1e-5).all(axis=1).sum())}")

@@ -10,7 +10,8 @@ import os
 LIB_PATH = Path(os.environ.get("TSIDB_LIB_PATH", _HERE / "libtsidb.so"))
 
 SYMBOLS = ["tsidb_dims", "tsidb_create", "tsidb_destroy", "tsidb_last_error", "tsidb_set_params", "tsidb_set_refs", "tsidb_reset",
-           "tsidb_tick", "tsidb_sim", "tsidb_step", "tsidb_rbd_terms", "tsidb_lds_bytes", "tsidb_walk_update", "tsidb_set_env_params", "tsidb_set_cop_ref"]
+           "tsidb_tick", "tsidb_sim", "tsidb_step", "tsidb_rbd_terms", "tsidb_lds_bytes", "tsidb_walk_update", "tsidb_set_env_params", "tsidb_set_cop_ref",
+           "tsidb_reset_done", "tsidb_set_posture_bias", "tsidb_walk_plan"]
 
 _libs = {}
 
@@ -72,6 +73,10 @@ def load(path=None):
     L.tsidb_set_cop_ref.argtypes = [vp, vp]
     L.tsidb_walk_update.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int] + [C.c_double] * 6 + [vp, vp, vp, vp, vp, C.c_double, vp, vp]
     L.tsidb_dims.argtypes = [C.POINTER(C.c_int)]
+    L.tsidb_reset_done.argtypes = [vp, vp, C.c_int] + [vp] * 7
+    L.tsidb_set_posture_bias.argtypes = [vp, vp]
+    L.tsidb_walk_plan.argtypes = [vp, vp, C.c_int, vp, C.c_int, vp, C.c_int, vp, vp, C.c_int, vp, vp, C.c_int, C.c_int] + [vp] * 9 + \
+                                 [C.c_double, vp, vp]
     for s in SYMBOLS:
         if s != "tsidb_last_error":
             getattr(L, s).restype = C.c_int

@@ -134,10 +134,15 @@ __global__ __launch_bounds__(WAVE) void k_rbd(const DevModel<T> *__restrict__ mp
 }
 
 // reset: standing state + references (WalkController.py:22-26,72-79,81,122,151-152,164-165; main.py:57-64)
+// done_rows (may be NULL): the [N, rows_ld] rows k_tick writes - only envs whose done flag (column NOBS + 1) is set are reset
+// (episode lifecycle on the device: no host round trip between `done` and the restart).  posture_bias (may be NULL, [NA]):
+// added to the captured posture reference (a walking workload's bent-knee posture).  frames (may be NULL): receives the
+// sole placements, as the host facade copies them after a reset.
 template <typename T>
 __global__ __launch_bounds__(WAVE) void k_reset(const DevModel<T> *__restrict__ mp, int n, const int *env_ids, int n_ids, T *q,
                                                 T *v, T *qpos, T *qvel, T *qacc_ws, T *com_ref, T *posture_ref,
-                                                T *foot_ref, T *contact_ref, uint8_t *cact, T *cop_frames, T *cop_ref) {
+                                                T *foot_ref, T *contact_ref, uint8_t *cact, T *cop_frames, T *cop_ref,
+                                                const T *done_rows, int rows_ld, const T *posture_bias, T *frames) {
   __shared__ TickLds<T> L;
   const DevModel<T> &m = *mp;
   const int lane = threadIdx.x;
@@ -148,6 +153,7 @@ __global__ __launch_bounds__(WAVE) void k_reset(const DevModel<T> *__restrict__ 
   }
   if (e < 0 || e >= n) return;
   const size_t E = (size_t)e;
+  if (done_rows && !(done_rows[E * rows_ld + NOBS + 1] != T(0))) return;
   if (lane < NQ) L.qs[lane] = m.q0[lane];
   if (lane < NV) L.vs[lane] = 0;
   __syncthreads();
@@ -174,6 +180,7 @@ __global__ __launch_bounds__(WAVE) void k_reset(const DevModel<T> *__restrict__ 
     T val = i < 3 ? L.oMf[f][9 + i] : L.oMf[f][3 * ((i - 3) % 3) + (i - 3) / 3];
     contact_ref[E * 24 + lane] = val;
     cop_frames[E * 24 + lane] = L.oMf[f][i];
+    if (frames) frames[E * 24 + lane] = L.oMf[f][i];
   }
   if (lane < 48) {
     const int i = lane % 24;
@@ -181,7 +188,7 @@ __global__ __launch_bounds__(WAVE) void k_reset(const DevModel<T> *__restrict__ 
     foot_ref[E * 48 + lane] = (i == 3 || i == 7 || i == 11) ? T(1) : T(0);
   }
   if (lane < 9) com_ref[E * 9 + lane] = lane < 3 ? L.com[lane] : T(0);
-  if (lane < NA) posture_ref[E * NA + lane] = L.qs[7 + lane];
+  if (lane < NA) posture_ref[E * NA + lane] = L.qs[7 + lane] + (posture_bias ? posture_bias[lane] : T(0));
   if (lane < 2) cact[E * 2 + lane] = 1;
   // CoP task reference: between the soles, on the floor
   if (cop_ref && lane < 3) cop_ref[E * 3 + lane] = lane < 2 ? T(0.5) * (L.oMf[0][9 + lane] + L.oMf[1][9 + lane]) : T(0);
@@ -295,6 +302,169 @@ __global__ __launch_bounds__(256) void k_walk(int n, const T *coef, const int *s
   }
 }
 
+// ---------------------------------------------------------------------------- episode plan on the device
+// One thread per env: everything a walking episode needs from a path - footsteps (ctrl/Footstep_Planner.py:92-125: a step
+// every step_length of accumulated path length at pos + t L/2 +- n W/2, yaw along the tangent, closing steps :114-123),
+// swing polynomials from footstep k to k + 2 (ctrl/Walk_Planner.py:23-31, ctrl/Foot_Trajectory.py:5-27: x, y, yaw linear,
+// z the parabola / cubic through the knots), rest placements, and the CoM plan: DCM end points backwards from the final
+// stand, then one LIPM segment (ctrl/LIPM.py:34-49 in closed form) per phase - the tables WalkSchedule.__init__ builds on
+// the host, so that a reset with a new path never leaves the GPU.  Arithmetic in float64 whatever the path's type.
+__device__ __forceinline__ unsigned long long plan_hash(unsigned long long seed, unsigned long long env, unsigned long long episode) {
+  unsigned long long x = seed ^ (env * 0x9E3779B97F4A7C15ull) ^ (episode * 0xD1B54A32D192ED03ull);
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+__device__ __forceinline__ void plan_poly(int nk, const double *x, const double *f, double *c) { // Newton's divided differences
+  double d1[3] = {0, 0, 0}, d2[2] = {0, 0}, d3 = 0;
+  for (int i = 0; i + 1 < nk; i++) d1[i] = (f[i + 1] - f[i]) / (x[i + 1] - x[i]);
+  for (int i = 0; i + 2 < nk; i++) d2[i] = (d1[i + 1] - d1[i]) / (x[i + 2] - x[i]);
+  if (nk == 4) d3 = (d2[1] - d2[0]) / (x[3] - x[0]);
+  const double x1 = nk > 2 ? x[1] : 0.0, x2 = nk > 3 ? x[2] : 0.0;
+  c[0] = f[0];
+  c[1] = d1[0] - d2[0] * x1 + d3 * x1 * x2;
+  c[2] = d2[0] - d3 * (x1 + x2);
+  c[3] = d3;
+}
+struct PlanParams { double v[16]; };
+template <typename T>
+__global__ __launch_bounds__(64) void k_plan(int n, const int *env_ids, int n_ids, const T *done_rows, int rows_ld, PlanParams PP,
+                                             const T *cop_frames, const T *com_ref, const double *path, const int *npts, int P,
+                                             const double *scale, int *episode, int bump, int K, double *steps, T *coef, int *side,
+                                             int *nsteps, T *rest, T *com, int *flags, T *t_offset, int *latch, double t_now,
+                                             const double *t_dev) {
+  const double *pp = PP.v;
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (env_ids) {
+    if (e >= n_ids) return;
+    e = env_ids[e];
+  }
+  if (e < 0 || e >= n) return;
+  const size_t E = (size_t)e;
+  if (done_rows && !(done_rows[E * rows_ld + NOBS + 1] != T(0))) return;
+  const double L = pp[0], Tst = pp[3], rise_ratio = pp[4], t_start = pp[5], foot_press = pp[7], ds = pp[8];
+  const T *fr = cop_frames + E * 24;
+  const double lf[2] = {(double)fr[9], (double)fr[10]}, rf[2] = {(double)fr[21], (double)fr[22]};
+  const double com0[3] = {(double)com_ref[E * 9], (double)com_ref[E * 9 + 1], (double)com_ref[E * 9 + 2]};
+  const double heading = atan2(-(lf[0] - rf[0]), lf[1] - rf[1]);
+  const double ch = cos(heading), sh = sin(heading), mid[2] = {0.5 * (lf[0] + rf[0]), 0.5 * (lf[1] + rf[1])};
+  double *st = steps + E * (K + 2) * 4; // x, y, yaw, side per footstep
+  int nst = 0, cut = 0;
+  auto put = [&](double x, double y, double yaw, int sd) { st[4 * nst] = x; st[4 * nst + 1] = y; st[4 * nst + 2] = yaw; st[4 * nst + 3] = sd; nst++; };
+  auto add_step = [&](double dx, double dy, int sd, const double *pos) {
+    if (nst >= K + 2) { cut = 1; return; }
+    const double nrm = sqrt(dx * dx + dy * dy), tx = dx / nrm, ty = dy / nrm, sign = sd == 0 ? 1.0 : -1.0;
+    put(pos[0] + tx * (pp[0] / 2) + (-ty) * (pp[1] / 2 * sign), pos[1] + ty * (pp[0] / 2) + tx * (pp[1] / 2 * sign), atan2(dy, dx), sd);
+  };
+  put(lf[0], lf[1], heading, 0);
+  put(rf[0], rf[1], heading, 1);
+  int sd = 1;
+  double travelled = 0, dx = 0, dy = 0, prev[2] = {0, 0}, a[2] = {0, 0}, sc = 1.0;
+  if (!path) {
+    if (episode && bump) episode[e] += 1;
+    if (scale) sc = scale[e];
+    else if (episode) sc = pp[13] + (pp[14] - pp[13]) * ((double)(plan_hash((unsigned long long)pp[15], (unsigned long long)e, (unsigned long long)episode[e]) >> 11) * (1.0 / 9007199254740992.0));
+  }
+  const int nv = path ? npts[e] : (int)pp[12];
+  double ux = 0, uy = 0, uth = 0;
+  for (int i = 0; i < nv; i++) {
+    double b[2];
+    if (path) { b[0] = path[(E * P + i) * 2]; b[1] = path[(E * P + i) * 2 + 1]; }
+    else {
+      ux += pp[9] * pp[11] * cos(uth); uy += pp[9] * pp[11] * sin(uth); uth += pp[10] * pp[11];
+      const double px = ux * sc, py = uy * sc;
+      b[0] = (ch * px - sh * py) + mid[0]; b[1] = (sh * px + ch * py) + mid[1];
+    }
+    if (i == 0) { prev[0] = a[0] = b[0]; prev[1] = a[1] = b[1]; continue; }
+    const double seg = sqrt((b[0] - a[0]) * (b[0] - a[0]) + (b[1] - a[1]) * (b[1] - a[1]));
+    int mres = ds > 0 ? (int)ceil(seg / ds) : 1;
+    if (mres < 1) mres = 1;
+    for (int j = 1; j <= mres; j++) {
+      const double qf = (double)j / mres, p[2] = {a[0] + (b[0] - a[0]) * qf, a[1] + (b[1] - a[1]) * qf};
+      dx = p[0] - prev[0]; dy = p[1] - prev[1];
+      travelled += hypot(dx, dy);
+      if (travelled >= L) { sd = !sd; add_step(dx, dy, sd, prev); travelled = 0; }
+      prev[0] = p[0]; prev[1] = p[1];
+    }
+    a[0] = b[0]; a[1] = b[1];
+  }
+  sd = !sd;
+  add_step(dx, dy, sd, prev);
+  if (travelled > 0) { sd = !sd; add_step(dx, dy, sd, prev); }
+  const int ns = nst - 2;
+  nsteps[e] = ns;
+  if (flags) flags[e] = cut;
+  for (int k = nst; k < K + 2; k++) st[4 * k] = st[4 * k + 1] = st[4 * k + 2] = st[4 * k + 3] = 0;
+  // swing polynomials and rest placements; yaw relative to the initial heading
+  double cur[2][4];
+  for (int s2 = 0; s2 < 2; s2++) {
+    const int f = (int)st[4 * s2 + 3];
+    cur[f][0] = st[4 * s2]; cur[f][1] = st[4 * s2 + 1]; cur[f][2] = st[4 * s2 + 2] - heading; cur[f][3] = 0;
+  }
+  for (int k = 0; k <= K; k++) {
+    T *ro = rest + (E * (K + 1) + k) * 8;
+    for (int i = 0; i < 8; i++) ro[i] = (T)cur[i / 4][i % 4];
+    if (k >= K) break;
+    double c[16];
+    for (int i = 0; i < 16; i++) c[i] = 0;
+    int sw = 0;
+    if (k < ns) {
+      sw = (int)st[4 * k + 3];
+      const double nxt[4] = {st[4 * (k + 2)], st[4 * (k + 2) + 1], st[4 * (k + 2) + 2] - heading, -foot_press};
+      const double x2[2] = {0, Tst};
+      double f2[2];
+      f2[0] = cur[sw][0]; f2[1] = nxt[0]; plan_poly(2, x2, f2, c + 0);
+      f2[0] = cur[sw][1]; f2[1] = nxt[1]; plan_poly(2, x2, f2, c + 4);
+      f2[0] = cur[sw][2]; f2[1] = nxt[2]; plan_poly(2, x2, f2, c + 12);
+      if (rise_ratio != 0.5) {
+        const double rise = Tst * rise_ratio, x4[4] = {0, rise, Tst - rise, Tst}, f4[4] = {cur[sw][3], cur[sw][3] + pp[2], nxt[3] + pp[2], nxt[3]};
+        plan_poly(4, x4, f4, c + 8);
+      } else {
+        const double x3[3] = {0, Tst * rise_ratio, Tst}, f3[3] = {cur[sw][3], cur[sw][3] + pp[2], nxt[3]};
+        plan_poly(3, x3, f3, c + 8);
+      }
+      for (int i = 0; i < 4; i++) cur[sw][i] = nxt[i];
+    }
+    T *co = coef + (E * K + k) * 16;
+    for (int i = 0; i < 16; i++) co[i] = (T)c[i];
+    side[E * K + k] = sw;
+  }
+  // CoM plan: DCM end points backwards (kept in the table's d slot), then forwards one LIPM segment per phase
+  const double w = sqrt(9.80665 / (com0[2] - pp[6])), ewT = exp(-w * Tst);
+  T *cm = com + E * (K + 2) * 6;
+  double fin[2] = {com0[0], com0[1]}, xi[2];
+  if (ns > 0) { fin[0] = 0.5 * (st[4 * ns] + st[4 * (ns + 1)]); fin[1] = 0.5 * (st[4 * ns + 1] + st[4 * (ns + 1) + 1]); }
+  xi[0] = fin[0]; xi[1] = fin[1];
+  for (int k = ns - 1; k >= 0; k--) // xi_k waits in the d slot of phase k + 1 for the forward pass (rounded to T there)
+    for (int ax = 0; ax < 2; ax++) { const double z = st[4 * (k + 1) + ax]; xi[ax] = z + (xi[ax] - z) * ewT; cm[((k + 1) * 2 + ax) * 3 + 1] = (T)xi[ax]; }
+  double x[2] = {com0[0], com0[1]};
+  const double ep0 = exp(w * t_start), em0 = exp(-w * t_start), epT = exp(w * Tst), emT = exp(-w * Tst);
+  for (int ax = 0; ax < 2; ax++) {
+    const double x0k = ns > 0 ? (sizeof(T) == 8 ? (double)cm[(1 * 2 + ax) * 3 + 1] : xi[ax]) : fin[ax];
+    const double z = (x0k - x[ax] * ep0) / (1.0 - ep0), d = x[ax] - z, c2 = (x[ax] - z) - 0.5 * d;
+    cm[ax * 3] = (T)z; cm[ax * 3 + 1] = (T)d; cm[ax * 3 + 2] = (T)c2;
+    x[ax] = z + (0.5 * d * ep0 + c2 * em0);
+  }
+  auto xi_at = [&](int k0, int ax) { // float32 tables cannot park a float64 DCM end point: run the recursion again from the end
+    double vv = fin[ax];
+    for (int k = ns - 1; k >= k0; k--) { const double z = st[4 * (k + 1) + ax]; vv = z + (vv - z) * ewT; }
+    return vv;
+  };
+  for (int k = 0; k < ns; k++)
+    for (int ax = 0; ax < 2; ax++) {
+      T *sg = cm + ((k + 1) * 2 + ax) * 3;
+      const double z = st[4 * (k + 1) + ax], d = (sizeof(T) == 8 ? (double)sg[1] : xi_at(k, ax)) - z, c2 = (x[ax] - z) - 0.5 * d;
+      sg[0] = (T)z; sg[1] = (T)d; sg[2] = (T)c2;
+      x[ax] = z + (0.5 * d * epT + c2 * emT);
+    }
+  for (int k = ns + 1; k < K + 2; k++)
+    for (int ax = 0; ax < 2; ax++) { T *sg = cm + (k * 2 + ax) * 3; sg[0] = (T)fin[ax]; sg[1] = 0; sg[2] = (T)(x[ax] - fin[ax]); }
+  // the env's clock restarts: its timeline runs on t - t_offset
+  if (t_offset) t_offset[e] = (T)(t_dev ? t_dev[0] : t_now);
+  if (latch) latch[e] = -1;
+}
+
 // ============================================================================ host side
 namespace {
 
@@ -401,7 +571,7 @@ struct tsidb_ctx {
   int *d_eadr = nullptr, *d_edge = nullptr;
   const void *com_ref = nullptr, *posture_ref = nullptr, *foot_ref = nullptr, *contact_ref = nullptr, *cop_frames = nullptr;
   const uint8_t *contact_active = nullptr;
-  const void *env_params = nullptr, *terrain = nullptr, *cop_ref = nullptr;
+  const void *env_params = nullptr, *terrain = nullptr, *cop_ref = nullptr, *posture_bias = nullptr;
   int foot_body[2] = {-1, -1}; // sim bodies that carry the left / right sole frame
   unsigned long long foot_geoms[2] = {0, 0}; // bit g: collision geom g is on that body
   std::string err;
@@ -683,6 +853,18 @@ static void launch_sim(tsidb_ctx *h, const void *q_tsid, const void *v_tsid, voi
   HIP_OK(hipGetLastError());
 }
 
+template <typename T>
+static void launch_reset(tsidb_ctx *h, const int32_t *env_ids, int n_ids, void *q, void *v, void *qpos, void *qvel, void *qacc_ws,
+                         const void *done_rows, int rows_ld, void *frames, hipStream_t s) {
+  const int grid = env_ids ? n_ids : h->num_envs;
+  if (grid <= 0) return;
+  hipLaunchKernelGGL(k_reset<T>, dim3(grid), dim3(WAVE), 0, s, (const DevModel<T> *)h->d_model, h->num_envs, env_ids, n_ids, (T *)q,
+                     (T *)v, (T *)qpos, (T *)qvel, (T *)qacc_ws, (T *)h->com_ref, (T *)h->posture_ref, (T *)h->foot_ref,
+                     (T *)h->contact_ref, (uint8_t *)h->contact_active, (T *)h->cop_frames, (T *)h->cop_ref, (const T *)done_rows,
+                     rows_ld, (const T *)h->posture_bias, (T *)frames);
+  HIP_OK(hipGetLastError());
+}
+
 extern "C" {
 
 int tsidb_create(const void *model_blob, size_t nbytes, const double *params, int n_params, int num_envs, int device,
@@ -780,19 +962,56 @@ int tsidb_reset(tsidb_handle h, const int32_t *env_ids, int n_ids, void *q, void
   GUARD_BEGIN
   need_refs(h);
   if (!q || !v || !qpos || !qvel || !qacc_ws) throw std::string("tsidb_reset: null state buffer");
-  const int grid = env_ids ? n_ids : h->num_envs;
-  if (grid <= 0) return 0;
+  if (h->dtype == TSIDB_F64) launch_reset<double>(h, env_ids, n_ids, q, v, qpos, qvel, qacc_ws, nullptr, 0, nullptr, (hipStream_t)stream);
+  else launch_reset<float>(h, env_ids, n_ids, q, v, qpos, qvel, qacc_ws, nullptr, 0, nullptr, (hipStream_t)stream);
+  GUARD_END
+}
+
+int tsidb_reset_done(tsidb_handle h, const void *rows, int rows_ld, void *q, void *v, void *qpos, void *qvel, void *qacc_ws,
+                     void *frames, void *stream) {
+  GUARD_BEGIN
+  need_refs(h);
+  if (!rows || rows_ld < NROW) throw std::string("tsidb_reset_done: needs the [N, >= TSIDB_NROW] rows tsidb_tick writes (done flag in column TSIDB_NOBS + 1)");
+  if (!q || !v || !qpos || !qvel || !qacc_ws) throw std::string("tsidb_reset_done: null state buffer");
+  if (h->dtype == TSIDB_F64) launch_reset<double>(h, nullptr, 0, q, v, qpos, qvel, qacc_ws, rows, rows_ld, frames, (hipStream_t)stream);
+  else launch_reset<float>(h, nullptr, 0, q, v, qpos, qvel, qacc_ws, rows, rows_ld, frames, (hipStream_t)stream);
+  GUARD_END
+}
+
+int tsidb_set_posture_bias(tsidb_handle h, const void *posture_bias) {
+  if (!h) return -1;
+  h->posture_bias = posture_bias;
+  return 0;
+}
+
+int tsidb_walk_plan(tsidb_handle h, const int32_t *env_ids, int n_ids, const void *done_rows, int rows_ld,
+                    const double *plan_params, int n_plan_params, const double *path, const int32_t *npts, int P,
+                    const double *scale, int32_t *episode, int bump_episode, int K, double *steps, void *coef, int32_t *side,
+                    int32_t *nsteps, void *rest, void *com, int32_t *flags, void *t_offset, int32_t *td_latch, double t,
+                    const double *t_device, void *stream) {
+  GUARD_BEGIN
+  need_refs(h);
+  if (!plan_params || n_plan_params != TSIDB_PLAN_NPARAMS) throw std::string("tsidb_walk_plan: plan_params must hold TSIDB_PLAN_NPARAMS doubles");
+  if (!steps || !coef || !side || !nsteps || !rest || !com || K <= 0) throw std::string("tsidb_walk_plan: null table or K <= 0");
+  if (path && (!npts || P < 2)) throw std::string("tsidb_walk_plan: an explicit path needs npts and P >= 2");
+  if (!path && !(plan_params[12] >= 2)) throw std::string("tsidb_walk_plan: the unicycle path needs at least two vertices");
+  if (!(plan_params[0] > 0) || !(plan_params[3] > 0) || !(plan_params[5] > 0) || !(plan_params[4] > 0 && plan_params[4] < 1))
+    throw std::string("tsidb_walk_plan: step_length, step_duration, t_start must be positive and rise_ratio inside (0, 1)");
+  if (done_rows && rows_ld < NROW) throw std::string("tsidb_walk_plan: the done mask needs rows of at least TSIDB_NROW values");
+  const int cnt = env_ids ? n_ids : h->num_envs;
+  if (cnt <= 0) return 0;
+  PlanParams PP;
+  for (int i = 0; i < 16; i++) PP.v[i] = plan_params[i];
   hipStream_t s = (hipStream_t)stream;
+  const int grid = (cnt + 63) / 64;
   if (h->dtype == TSIDB_F64)
-    hipLaunchKernelGGL(k_reset<double>, dim3(grid), dim3(WAVE), 0, s, (const DevModel<double> *)h->d_model, h->num_envs,
-                       env_ids, n_ids, (double *)q, (double *)v, (double *)qpos, (double *)qvel, (double *)qacc_ws,
-                       (double *)h->com_ref, (double *)h->posture_ref, (double *)h->foot_ref, (double *)h->contact_ref,
-                       (uint8_t *)h->contact_active, (double *)h->cop_frames, (double *)h->cop_ref);
+    hipLaunchKernelGGL(k_plan<double>, dim3(grid), dim3(64), 0, s, h->num_envs, env_ids, n_ids, (const double *)done_rows, rows_ld, PP,
+                       (const double *)h->cop_frames, (const double *)h->com_ref, path, npts, P, scale, episode, bump_episode, K, steps,
+                       (double *)coef, side, nsteps, (double *)rest, (double *)com, flags, (double *)t_offset, td_latch, t, t_device);
   else
-    hipLaunchKernelGGL(k_reset<float>, dim3(grid), dim3(WAVE), 0, s, (const DevModel<float> *)h->d_model, h->num_envs,
-                       env_ids, n_ids, (float *)q, (float *)v, (float *)qpos, (float *)qvel, (float *)qacc_ws,
-                       (float *)h->com_ref, (float *)h->posture_ref, (float *)h->foot_ref, (float *)h->contact_ref,
-                       (uint8_t *)h->contact_active, (float *)h->cop_frames, (float *)h->cop_ref);
+    hipLaunchKernelGGL(k_plan<float>, dim3(grid), dim3(64), 0, s, h->num_envs, env_ids, n_ids, (const float *)done_rows, rows_ld, PP,
+                       (const float *)h->cop_frames, (const float *)h->com_ref, path, npts, P, scale, episode, bump_episode, K, steps,
+                       (float *)coef, side, nsteps, (float *)rest, (float *)com, flags, (float *)t_offset, td_latch, t, t_device);
   HIP_OK(hipGetLastError());
   GUARD_END
 }

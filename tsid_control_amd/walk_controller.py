@@ -94,6 +94,7 @@ class WalkController:
         self.v_max = conf.v_max_scaling * self.model.velocity_limit
         self.v_min = -self.v_max
         self.LF_frame, self.RF_frame = 0, 1
+        self.posture_bias = None
         self.t = 0.0
         b = int(getattr(conf, "pipeline_sim_batch", 0))
         # 0 = auto: small batches are latency bound, there the barrier packets of the per-step cross-stream handshake are
@@ -191,9 +192,37 @@ class WalkController:
                             floor_offset=torch.zeros(N, dtype=torch.float64), terrain=terrain)
 
     # ------------------------------------------------------------------ reset / step
-    def reset(self, env_ids=None):
+    def set_posture_bias(self, bias):
+        """[NA] offsets every reset adds to the posture reference it captures (ctrl/WalkController.py:164-165 takes q0's
+        joints; a walking workload keeps its knees bent: walk_planner.op3_walking_posture()).  Also applied to the
+        current posture references; None removes it."""
+        old = self.posture_bias
+        new = None if bias is None else torch.as_tensor(np.asarray(bias), device=self.device).to(self.dtype).contiguous()
+        if old is not None:
+            self.posture_ref -= old
+        if new is not None:
+            self.posture_ref += new
+        self.posture_bias = new
+        _lib.check(self._L, self._h, self._L.tsidb_set_posture_bias(self._h, _ptr(new)), "tsidb_set_posture_bias")
+
+    def reset_done(self, sched=None, t=None, new_paths=True):
+        """Episode lifecycle on the device: reset every env whose done flag (self.done, written by the last tick) is set -
+        standing state, references, sim state - and, with a WalkSchedule.on_device schedule, rebuild its plan (a new path
+        when new_paths) and restart its clock at time t (default self.t, the time of the next tick).  Nothing comes back
+        to the host; envs that are not done are untouched."""
+        self.sync_sim()
+        with torch.cuda.device(self.device):
+            rc = self._L.tsidb_reset_done(self._h, _ptr(self.rows), self.NROW, _ptr(self.q), _ptr(self.v), _ptr(self.qpos),
+                                          _ptr(self.qvel), _ptr(self.qacc_warmstart), _ptr(self.frames), self._stream())
+        _lib.check(self._L, self._h, rc, "tsidb_reset_done")
+        if sched is not None:
+            sched.plan(self, t=self.t if t is None else t, done_only=True, new_paths=new_paths)
+
+    def reset(self, env_ids=None, sched=None, t=None, new_paths=False):
         """Standing state with the soles on z = 0 and all references re-captured
-        (WalkController.py:22-26,72-79,81,122,151-152,164-165; main.py:57-64)."""
+        (WalkController.py:22-26,72-79,81,122,151-152,164-165; main.py:57-64).  sched (a WalkSchedule.on_device
+        schedule): the reset envs' plans are rebuilt on the device (new paths when new_paths) and their clocks restart at
+        time t (default: self.t after the reset, i.e. 0 for a full reset)."""
         self.sync_sim()  # step_pipelined() may have left a sim stage running on the side stream
         ids = None
         n_ids = 0
@@ -211,6 +240,8 @@ class WalkController:
             self.t = 0.0
         else:
             self.frames[ids.long()] = self.cop_frames[ids.long()]
+        if sched is not None:
+            sched.plan(self, env_ids=ids, t=self.t if t is None else t, new_paths=new_paths)
 
     def step(self, n_substeps: int = 1):
         """One env step for every env: TSID tick (main.py:119-129) then, if conf.sim_enabled, base

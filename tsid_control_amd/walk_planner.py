@@ -90,6 +90,20 @@ def op3_walking_posture(bend=0.45):
     return p
 
 
+PLAN_NPARAMS = 16
+
+
+def plan_params(conf: RobotConfig, t_start=1.0, com_drop=0.015, foot_press=0.002, resample_ds=None, unicycle=(0.5, 0.1, 0.1, 100),
+                scale_range=(0.5, 1.0), seed=1):
+    """The 16 numbers tsidb_walk_plan takes (include/tsidb.h): step_length, step_width, step_height, step_duration,
+    rise_ratio (ctrl/conf.py:24-28), t_start, com_drop, foot_press, resample_ds (default step_length / 10; 0 = path
+    vertices as given), the unicycle path v, w, dt, n (Footstep_Planner.py:131-141), the range the per-env path scale is
+    drawn from, the seed of that draw."""
+    ds = conf.step_length / 10 if resample_ds is None else resample_ds
+    return np.array([conf.step_length, conf.step_width, conf.step_height, conf.step_duration, conf.rise_ratio, t_start, com_drop,
+                     foot_press, ds, *unicycle, *scale_range, float(seed)], dtype=np.float64)
+
+
 class WalkSchedule:
     """Per-env walking tables, evaluated each tick on the device (no host round trip).
 
@@ -175,6 +189,69 @@ class WalkSchedule:
         self.device, self.dtype = device, dtype
         self.t_offset = None  # [N] per-env start delay (set_phase_offsets); None = every env on the same clock
         self.td_latch, self.td_fraction = None, 0.6  # contact-timing feedback (enable_touchdown_feedback)
+
+    @classmethod
+    def on_device(cls, wc, conf: RobotConfig = None, K=104, t_start=1.0, com_drop=0.015, foot_press=0.002, seed=1,
+                  scale_range=(0.5, 1.0), unicycle=(0.5, 0.1, 0.1, 100), resample_ds=None, scale=None, plan=True):
+        """A schedule whose tables live on the device from the start and are BUILT there (tsidb_walk_plan): K = capacity
+        in steps per env; every env walks the reference's demo unicycle path (Footstep_Planner.py:131-141) scaled by
+        scale[e] if given, else by U(scale_range) drawn on the device from hash(seed, env, episode[e]).  plan(...) /
+        restart via WalkController.reset(env_ids, sched=...) / reset_done(sched) replan single envs without touching
+        the host.  (Vertex spacing resample_ds = step_length / 10 by default: a path whose pieces add up to exactly one
+        step_length - scales that are multiples of 0.1 - leaves `travelled >= step_length`, Footstep_Planner.py:106, to
+        rounding, and two implementations may then differ by one vertex in where a step lands.)"""
+        self = cls.__new__(cls)
+        conf = conf if conf is not None else wc.conf
+        self.conf, self.N, self.K = conf, wc.num_envs, int(K)
+        self.device, self.dtype = wc.device, wc.dtype
+        N, dev = self.N, wc.device
+        z = lambda *sh, dt=wc.dtype: torch.zeros(*sh, dtype=dt, device=dev)
+        self.coef, self.rest, self.com = z(N, K, 4, 4), z(N, K + 1, 2, 4), z(N, K + 2, 2, 3)
+        self.side, self.nsteps = z(N, K, dt=torch.int32), z(N, dt=torch.int32)
+        self.steps, self.flags = z(N, K + 2, 4, dt=torch.float64), z(N, dt=torch.int32)
+        self.episode = z(N, dt=torch.int32)
+        self.scale = None if scale is None else torch.as_tensor(scale, dtype=torch.float64, device=dev).contiguous()
+        self.t_offset = z(N)
+        self.td_latch, self.td_fraction = None, 0.6
+        self._side32, self._nsteps32, self._coef_c, self._rest_c, self._com_c = self.side, self.nsteps, self.coef, self.rest, self.com
+        self.pp = plan_params(conf, t_start, com_drop, foot_press, resample_ds, unicycle, scale_range, seed)
+        self.t_start, self.dz = float(t_start), float(com_drop)
+        self.z0 = float(wc.com_ref[0, 2])   # (standing CoM height: the same for every env right after a reset)
+        self.omega = float(np.sqrt(GRAVITY / (self.z0 - self.dz)))
+        if plan:
+            self.plan(wc)
+        return self
+
+    def plan(self, wc, env_ids=None, t=0.0, done_only=False, new_paths=False, path=None, npts=None, t_device=None):
+        """(Re)build the plan of the selected envs ON THE DEVICE and restart their clocks at time t (env time = t' - t
+        from then on; the touch-down latch is cleared): env_ids = list / tensor (None = all), done_only = only envs
+        whose done flag is set in wc.rows (no host sync), new_paths = advance the env's episode counter first, i.e. draw
+        a new path scale.  path [N,P,2] float64 + npts [N]: explicit polylines (world coordinates) instead of the
+        unicycle path.  Needs the envs' standing state in wc.cop_frames / wc.com_ref (a reset puts it there)."""
+        import ctypes as C
+        from . import _lib
+        if not hasattr(self, "pp"):
+            raise _lib.TsidbError("this schedule was built on the host (WalkSchedule(...)): use WalkSchedule.on_device")
+        ids, n_ids = None, 0
+        if env_ids is not None:
+            ids = torch.as_tensor(env_ids, dtype=torch.int32, device=self.device).contiguous()
+            n_ids = ids.numel()
+            if n_ids == 0:
+                return
+        p = lambda x: C.c_void_p(x.data_ptr()) if x is not None else None
+        if path is not None:
+            path = torch.as_tensor(path, dtype=torch.float64, device=self.device).contiguous()
+            npts = torch.as_tensor(npts, dtype=torch.int32, device=self.device).contiguous()
+            self._path_keep = (path, npts)
+        use_rng = path is None and self.scale is None
+        with torch.cuda.device(wc.device):
+            rc = wc._L.tsidb_walk_plan(wc._h, p(ids), n_ids, p(wc.rows) if done_only else None, wc.NROW,
+                                       self.pp.ctypes.data_as(C.c_void_p), PLAN_NPARAMS, p(path), p(npts),
+                                       int(path.shape[1]) if path is not None else 0, p(self.scale), p(self.episode) if use_rng else None,
+                                       int(bool(new_paths)), self.K, p(self.steps), p(self.coef), p(self.side), p(self.nsteps),
+                                       p(self.rest), p(self.com), p(self.flags), p(self.t_offset), p(self.td_latch), float(t),
+                                       p(t_device), wc._stream())
+        _lib.check(wc._L, wc._h, rc, "tsidb_walk_plan")
 
     def enable_touchdown_feedback(self, fraction=0.6):
         """Closed loop: take a step's touch-down as soon as the sim reports the swing foot on the floor after
@@ -288,7 +365,7 @@ class WalkSchedule:
         float64 tensor holding the time - read by the kernel instead of `t` (graph capture)."""
         import ctypes as C
         from . import _lib
-        if not hasattr(self, "_side32"):
+        if not hasattr(self, "_side32"):   # (host-built schedule: int32 / contiguous copies for the kernel)
             self._side32 = self.side.to(torch.int32).contiguous()
             self._nsteps32 = self.nsteps.to(torch.int32).contiguous()
             self._coef_c, self._rest_c, self._com_c = self.coef.contiguous(), self.rest.contiguous(), self.com.contiguous()
