@@ -45,6 +45,10 @@ enum {
    * frictionloss (robot.xml:8), rotor inertia added to the diagonal of TSID's mass matrix on the actuated joints (the sim
    * has armature 0.005, the URDF none), Coulomb-friction feed-forward added to tau [N m] */
   TSIDB_P_SIM_FLOSS_SCALE, TSIDB_P_TSID_ARMATURE, TSIDB_P_FRICTION_COMP,
+  /* sim: plane <-> mesh multi-contact rule (main.py:195, mj_step's plane-convex routine).  0: the support vertex plus EVERY
+   * hull-graph neighbour of it within the margin; 1: upstream's rule as far as it is known here (mujoco is not available to
+   * check): in graph order at most 3 more contacts, each at least 0.3 x the geom's bounding radius from the first */
+  TSIDB_P_PLANE_MESH,
   TSIDB_P_COUNT = 128
 };
 
@@ -103,7 +107,11 @@ int tsidb_tick(tsidb_handle h, void *q, void *v, void *tau, void *dv, void *f, i
  * the TSID state moves).  qpos [N,27], qvel [N,26], qacc_ws [N,26] updated in place; qacc [N,26], ncon [N],
  * con_pairs [N,32] = (geom << 16 | hull vertex) for floor contacts, (geom2 << 16 | 0x8000 | geom1) for robot<->robot
  * ones, -1 padded (geom = collision geom in the blob's order; the v1 robot has one per body, in body order);
- * info [N,4] slots 2,3 = solver iterations, failure bits (all may be NULL). */
+ * info [N,4] slots 2,3 = solver iterations, flag bits (all may be NULL).  Flag bits: 1 the damped-Euler matrix, 2 the Newton
+ * Hessian was not positive definite (the step ends with what it has); 4 the step was skipped (non-finite or diverged state /
+ * targets); 8 a penetrating contact was dropped at a cap (TSIDB_MAXCON contacts per env, 12 of them robot<->robot);
+ * 16 a support vertex has more than 63 hull-graph neighbours (the rest is not looked at); 32 more than 64 candidate pairs
+ * survived the mid phase (the rest is not collided). */
 int tsidb_sim(tsidb_handle h, const void *q_tsid, const void *v_tsid, void *qpos, void *qvel, void *qacc_ws,
               void *qacc, int32_t *ncon, int32_t *con_pairs, int32_t *info, void *stream);
 

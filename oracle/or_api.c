@@ -49,6 +49,7 @@ int or_env_step_batch_walk(const OrModel *m, const double *params, int n, double
                            int32_t *status, double *obs, int32_t *ncon, int32_t *con_geom, int nthreads,
                            const OrWalkTables *w, double *frames, double *rewdone, const double *terrain, const double *cop_ref) {
   ((OrModel *)m)->floss_scale = params[P_SIM_FLOSS_SCALE] != 0.0 ? params[P_SIM_FLOSS_SCALE] : 1.0;
+  ((OrModel *)m)->plane_mesh = params[P_PLANE_MESH] != 0.0;
   const int sim = params[P_SIM_ENABLED] != 0.0;
   const int closed = params[P_CLOSED_LOOP] != 0.0;
   const int quirks = params[P_QUIRKS] != 0.0 && !closed;

@@ -286,8 +286,8 @@ static int boxes_overlap(const double *Ra, const double *ca, const double *ha, c
 
 /* Robot<->robot contacts for one env: every candidate geom pair (mj_pairs order) through bounding spheres, boxes,
  * MPR.  Rb / pb: world placements of the bodies.  Appends at most OR_MAXHH contacts (and never beyond OR_MAXCON in
- * total); returns the number appended, *overflow set when a penetrating pair had to be dropped (also when more than
- * 64 pairs survive the mid phase: the device works through at most one wavefront's worth of candidates). */
+ * total); returns the number appended; *overflow bit 0: a penetrating pair had to be dropped at a cap, bit 1: more than
+ * 64 pairs survived the mid phase (the device works through at most one wavefront's worth of candidates). */
 int or_collide_pairs(const OrModel *m, const double Rb[][9], const double pb[][3], int ncon0, int *geom1, int *geom2,
                      double *dist, double (*pos)[3], double (*nrm)[3], int *overflow) {
   int n = 0, ncand = 0;
@@ -309,10 +309,10 @@ int or_collide_pairs(const OrModel *m, const double Rb[][9], const double pb[][3
     const double ha[3] = {m->hull_box[a][3] + hm, m->hull_box[a][4] + hm, m->hull_box[a][5] + hm};
     const double hb[3] = {m->hull_box[b][3] + hm, m->hull_box[b][4] + hm, m->hull_box[b][5] + hm};
     if (!boxes_overlap(Rb[Ba], ba, ha, Rb[Bb], bb, hb)) continue;
-    if (++ncand > 64) { *overflow = 1; break; }
+    if (++ncand > 64) { *overflow |= 2; break; }
     double depth, dir[3], p[3];
     if (!or_mpr_penetration_margin(m, a, Rb[Ba], pb[Ba], b, Rb[Bb], pb[Bb], margin, &depth, dir, p)) continue;
-    if (n >= OR_MAXHH || ncon0 + n >= OR_MAXCON) { *overflow = 1; continue; }
+    if (n >= OR_MAXHH || ncon0 + n >= OR_MAXCON) { *overflow |= 1; continue; }
     geom1[n] = a; geom2[n] = b;
     dist[n] = margin - depth;
     memcpy(pos[n], p, 24);

@@ -72,6 +72,8 @@ OrModel *or_model_load(const void *blob, size_t nbytes) {
   if (!OR_HAS_SIM) { /* TSID-only robot: no sim sections */
     if (e) { or_model_free(m); return NULL; }
     m->floss_scale = 1.0;
+  m->plane_mesh = 0;
+    m->plane_mesh = 0;
     m->foot_body[0] = m->foot_body[1] = -1;
     return m;
   }
@@ -118,6 +120,7 @@ OrModel *or_model_load(const void *blob, size_t nbytes) {
   for (int i = 0; i < OR_NV; i++) s += m->mj_dof_M0[i];
   m->meaninertia = s / OR_NV;
   m->floss_scale = 1.0;
+  m->plane_mesh = 0;
   {
     int s2t[OR_NA];
     m->foot_body[0] = m->foot_body[1] = -1;
@@ -139,3 +142,6 @@ void or_model_free(OrModel *m) {
   free(m->owned);
   free(m);
 }
+
+/* sim-stage option that the single-env entry points take from the model (the batch entry points set it from params) */
+void or_model_set_plane_mesh(OrModel *m, int rule) { m->plane_mesh = rule != 0; }

@@ -360,7 +360,7 @@ int or_sim_step_ext(const OrModel *m, double *qpos, double *qvel, const double *
   if (terr) for (int i = 0; i < 16; i++) hmax = fmax(hmax, terr[4 + i]);
   const double margin = m->contact[10]; /* max of the two geoms' margins: the floor inherits the robot's (robot/v0/robot.xml:4,59) */
   int ncon = 0;
-  for (int g = 0; g < OR_NG && ncon < OR_MAXCON; g++) {
+  for (int g = 0; g < OR_NG; g++) {
     const int b = m->geom_body[g];
     double cw[3];
     matvec(Rb[b], m->rbound[g], cw);
@@ -399,13 +399,29 @@ int or_sim_step_ext(const OrModel *m, double *qpos, double *qvel, const double *
     int cand[64], nc = 0;
     cand[nc++] = best;
     for (int e = m->hull_eadr[best]; e < m->hull_eadr[best + 1] && nc < 64; e++) cand[nc++] = v0 + m->hull_edge[e];
-    for (int c = 0; c < nc && ncon < OR_MAXCON; c++) {
+    if (m->hull_eadr[best + 1] - m->hull_eadr[best] > 63) info->flags |= 16;
+    /* plane <-> mesh multi-contact rule.  0: every neighbour within the margin.  1 (upstream's mjc_PlaneConvex, as far as
+     * it is known here): in graph order, at most 3 more contacts, each at least 0.3 rbound away from the FIRST one */
+    double first[3] = {0, 0, 0};
+    int extra = 0;
+    for (int c = 0; c < nc; c++) {
       const double *v = m->hull_vert + 3 * cand[c];
       double w[3];
       matvec(Rb[b], v, w);
       for (int i = 0; i < 3; i++) w[i] += pb[b][i];
       double dist = dot3(nrm, w) - pd - or_terrain_height(terr, w[0], w[1]);
       if (c > 0 && dist > margin) continue;
+      double cp[3];
+      for (int i = 0; i < 3; i++) cp[i] = w[i] - 0.5 * dist * nrm[i];
+      if (m->plane_mesh) {
+        if (c == 0) memcpy(first, cp, sizeof cp);
+        else {
+          const double d3[3] = {cp[0] - first[0], cp[1] - first[1], cp[2] - first[2]}, thr = 0.3 * m->rbound[g][3];
+          if (extra >= 3 || dot3(d3, d3) < thr * thr) continue;
+          extra++;
+        }
+      }
+      if (ncon >= OR_MAXCON) { info->flags |= 8; break; }
       info->con_geom[ncon] = g;
       info->con_body2[ncon] = b;
       info->con_vert[ncon] = cand[c] - v0;
@@ -431,7 +447,8 @@ int or_sim_step_ext(const OrModel *m, double *qpos, double *qvel, const double *
       info->con_dist[ncon] = hd[k];
       memcpy(info->con_pos[ncon], hp[k], 24);
     }
-    if (over) info->flags |= 8;
+    if (over & 1) info->flags |= 8;
+    if (over & 2) info->flags |= 32;
   }
   info->ncon = ncon;
 

@@ -46,7 +46,7 @@ enum {
   P_KP_POSTURE = P_CPOINTS + 12 /*20*/, P_KD_POSTURE = P_KP_POSTURE + 20,
   P_TAU_MAX = P_KD_POSTURE + 20, P_V_MAX = P_TAU_MAX + 20, P_MAX_ITER = P_V_MAX + 20,
   P_SIM_ENABLED, P_CLOSED_LOOP, P_W_AM, P_KP_AM /*3*/, P_REW_SIGMA = P_KP_AM + 3, P_REW_CTAU, P_DONE_HEIGHT, P_DONE_TILT,
-  P_SELF_COLLISION, P_W_COP, P_SIM_FLOSS_SCALE, P_TSID_ARMATURE, P_FRICTION_COMP, P_COUNT = 128
+  P_SELF_COLLISION, P_W_COP, P_SIM_FLOSS_SCALE, P_TSID_ARMATURE, P_FRICTION_COMP, P_PLANE_MESH, P_COUNT = 128
 };
 
 typedef struct {
@@ -84,6 +84,8 @@ typedef struct {
   int foot_body[2];   /* sim bodies carrying the left / right sole frame */
   uint64_t foot_geoms[2]; /* bit g set: geom g is on that body */
   double floss_scale; /* closed-loop knob params[P_SIM_FLOSS_SCALE] (1 = robot.xml:8), set by the batch entry points */
+  int plane_mesh;     /* params[P_PLANE_MESH]: 0 = every hull-graph neighbour of the support vertex within the margin is a contact;
+                       * 1 = upstream's plane <-> mesh rule (at most 3 more, each at least 0.3 rbound from the first) */
   void *owned;
 } OrModel;
 
@@ -144,6 +146,8 @@ int or_tsid_tick_cop(const OrModel *m, const double *params, double *q, double *
                      const uint8_t *contact_active, const double *cop_frames, const double *cop_ref, double *tau,
                      double *dv, double *f, double *obs, int *iters);
 
+void or_model_set_plane_mesh(OrModel *m, int rule); /* OrModel.plane_mesh for the single-env entry points */
+
 /* MuJoCo-subset step for one env: main.py:195 */
 typedef struct {
   int ncon, nefc, solver_iter;
@@ -154,7 +158,8 @@ typedef struct {
   double qacc[OR_NV], qacc_smooth[OR_NV], qfrc_bias[OR_NV], qfrc_actuator[OR_NV], M[OR_NV][OR_NV];
   int con_body1[OR_MAXCON];      /* body of geom1; -1 = floor */
   double con_frame[OR_MAXCON][3]; /* contact normal (geom1 -> geom2), world */
-  int flags;                      /* bit 3 (8): a penetrating robot<->robot pair was dropped (contact caps) */
+  int flags;                      /* 8: a contact was dropped at a cap (OR_MAXCON, OR_MAXHH); 16: a support vertex has more than 63
+                                   * hull-graph neighbours (the rest is not looked at); 32: more than 64 pairs survived the mid phase */
   int con_body2[OR_MAXCON];      /* body of geom2 */
   int newton_full, newton_rank1; /* Newton Hessian factorisations from scratch / rows applied as rank-1 updates */
 } OrSimInfo;

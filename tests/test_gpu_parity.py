@@ -969,7 +969,7 @@ def test_robot_robot_hull_contacts_f64(oracle):
             hh = r["con_body1"] >= 0
             n_hh += int(hh.sum())
             cross |= any(a not in anc(int(b)) and b not in anc(int(a)) for a, b in zip(r["con_body1"][hh], r["con_geom"][hh]))
-            assert r["flags"] == int(wc.info[e, 3]) & 8
+            assert r["flags"] == int(wc.info[e, 3]) & (8 | 16 | 32)
         assert diff(wc.qpos, qpos) < 1e-8 and diff(wc.qvel, qvel) < 1e-5, i
     assert n_hh > 100 and cross     # both the tree-sparse and the dense Newton Hessian paths ran
     assert bool(torch.isfinite(wc.qpos).all())
@@ -1016,7 +1016,12 @@ def test_config5_full_size_properties():
     q0, v0 = wc.q.clone(), wc.v.clone()
     for _ in range(30):
         wc.step()
-    assert int((wc.status != 0).sum()) == 0 and int((wc.info[:, 3] != 0).sum()) == 0
+    # no failed QP, no solver failure / skipped step (bits 1, 2, 4).  The contact caps are reported since round 3 (silent
+    # before) and a few envs in 65 536 do hit them: the base is teleported to the TSID pose every step (main.py:192), and on a
+    # floor tilted up under it a sole is pushed in far enough for more than TSIDB_MAXCON vertices to be inside the margin
+    # (bit 8), or the support vertex is one of the 18 (of 11 335) with more than 63 hull-graph neighbours (bit 16)
+    assert int((wc.status != 0).sum()) == 0 and int(((wc.info[:, 3] & (7 | 32)) != 0).sum()) == 0
+    assert int((wc.info[:, 3] != 0).sum()) < n // 1000
     for t in (wc.q, wc.v, wc.qpos, wc.qvel, wc.tau, wc.rows):
         assert bool(torch.isfinite(t).all())
     assert float((wc.qpos[:, 3:7].norm(dim=1) - 1).abs().max()) < 1e-12
@@ -1302,3 +1307,46 @@ def test_reset_with_schedule_restarts_the_walk():
         assert float((A.q[5] - q).abs().max()) < 1e-9 and float((A.tau[5] - tau).abs().max()) < 1e-6 and float((A.qpos[5] - qpos).abs().max()) < 1e-8
     A.reset(env_ids=[9], sched=sa, t=400 * dt, new_paths=True)
     assert int(sa.episode[9]) == 1 and int(sa.episode[5]) == 0
+
+
+@pytest.mark.parametrize("rule", ["all", "mujoco"])
+def test_plane_mesh_rule_matches_oracle(oracle, rule):
+    """a9 fidelity switch (conf.sim_plane_mesh): both plane <-> mesh multi-contact rules, HIP vs oracle, pair lists bit-exact -
+    perturbed standing envs pressed 2 mm into the floor so that many sole vertices are inside the margin"""
+    n = 24
+    wc = make(n, sim_plane_mesh=rule)
+    perturb(wc, 31, dq=0.02, dv=0.02)
+    wc.q[:, 2] -= 0.002
+    st = mirror(wc)
+    nmax = 0
+    for i in range(20):
+        wc.step()
+        oracle.env_step_batch(wc.params, st, nthreads=8)
+        assert np.array_equal(wc.ncon.cpu().numpy(), st["ncon"]) and np.array_equal(wc.con_pairs.cpu().numpy(), st["con_geom"]), i
+        assert diff(wc.qpos, st["qpos"]) < 1e-9 and diff(wc.qvel, st["qvel"]) < 1e-6, i
+        nmax = max(nmax, int(wc.ncon.max()))
+    per_geom = max(int((wc.con_pairs[e, :int(wc.ncon[e])] >> 16).bincount().max()) for e in range(n) if int(wc.ncon[e]) > 0)
+    assert (per_geom <= 4) if rule == "mujoco" else (nmax > 8)
+    assert int((wc.info[:, 3] != 0).sum()) == 0
+
+
+def test_contact_caps_are_flagged(oracle):
+    """silent caps are not silent: a robot lying on the floor makes more floor contacts than TSIDB_MAXCON - bit 8 of info[:, 3],
+    on the device as in the oracle"""
+    n = 4
+    wc = make(n, self_collision=True)
+    quats = torch.tensor([[0.7071068, 0.7071068, 0, 0], [0.7071068, 0, 0.7071068, 0], [0.5, 0.5, 0.5, 0.5], [1.0, 0, 0, 0]],
+                         dtype=wc.dtype, device=wc.device)
+    wc.qpos[:, 3:7] = quats
+    wc.qpos[:3, 2] = 0.03
+    qpos, qvel, ws = (x.cpu().numpy().copy() for x in (wc.qpos, wc.qvel, wc.qacc_warmstart))
+    wc.sim_step(teleport=False)
+    flagged = 0
+    for e in range(n):
+        r = oracle.sim_step(qpos[e], qvel[e], np.zeros(20), ws[e], self_collision=True)
+        assert r["flags"] == int(wc.info[e, 3]) & (8 | 16 | 32), e
+        assert r["ncon"] == int(wc.ncon[e])
+        flagged += int(bool(r["flags"] & 8))
+        if r["flags"] & 8:
+            assert r["ncon"] == 32
+    assert flagged >= 1 and int(wc.info[3, 3]) == 0     # the standing env is not flagged

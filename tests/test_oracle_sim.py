@@ -134,3 +134,30 @@ def test_diverged_state_skips_the_step(oracle):
     qvel[2] = -9e5                                            # fast, but inside the bound: stepped
     r = oracle.sim_step(qpos, qvel, np.zeros(20), ws)
     assert r["rc"] == 0 and qpos[2] < -1000
+
+
+def test_plane_mesh_rule_switch(oracle, blob, standing):
+    """a9 fidelity switch: 'all' takes the support vertex and EVERY hull-graph neighbour within the margin; 'mujoco' (upstream's
+    plane-convex rule as far as it is known here) at most 3 more per geom, each at least 0.3 x the geom's bounding radius from
+    the first contact.  Both see the same support vertices; flat feet pressed into the floor show the difference."""
+    rb = np.asarray(blob["mj_rbound"]).reshape(-1, 4)
+    res = {}
+    for rule in ("all", "mujoco"):
+        qpos = np.concatenate([standing["q"][:3], standing["q"][[6, 3, 4, 5]], np.zeros(20)])
+        qpos[2] -= 0.002                       # soles 2 mm into the floor: every sole vertex is inside the margin
+        qvel, ws = np.zeros(26), np.zeros(26)
+        res[rule] = oracle.sim_step(qpos, qvel, np.zeros(20), ws, plane_mesh=rule)
+    a, m = res["all"], res["mujoco"]
+    assert a["flags"] == 0 and m["flags"] == 0
+    feet = sorted(set(a["con_geom"].tolist()))
+    assert len(feet) == 2 and sorted(set(m["con_geom"].tolist())) == feet
+    for g in feet:
+        ia, im = np.nonzero(a["con_geom"] == g)[0], np.nonzero(m["con_geom"] == g)[0]
+        assert len(ia) > 4 and 1 <= len(im) <= 4
+        assert a["con_vert"][ia[0]] == m["con_vert"][im[0]]                       # same support vertex first
+        assert set(m["con_vert"][im].tolist()) <= set(a["con_vert"][ia].tolist())  # a subset, in the same graph order
+        d = np.linalg.norm(m["con_pos"][im[1:]] - m["con_pos"][im[0]], axis=1)
+        assert (d >= 0.3 * rb[g, 3] - 1e-12).all()
+    # the robot is held up either way: total normal force = weight within the solver's soft-contact compliance
+    for r in (a, m):
+        assert abs(r["qacc"][2]) < 50.0 and r["rc"] == 0

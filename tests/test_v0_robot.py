@@ -297,7 +297,7 @@ def test_v0_sim_step_matches_oracle_on_gpu(v0):
             want = np.full(32, -1, dtype=np.int32)
             want[:r["ncon"]] = (r["con_geom"] << 16) | r["con_vert"]
             assert np.array_equal(wc.con_pairs[e].cpu().numpy(), want), (i, e)
-            assert r["flags"] == int(wc.info[e, 3]) & 8
+            assert r["flags"] == int(wc.info[e, 3]) & (8 | 16 | 32)
             n_hh += int((r["con_body1"] >= 0).sum()); n_fl += int((r["con_body1"] < 0).sum())
         assert d(wc.qpos, qpos) < 1e-7 and d(wc.qvel, qvel) < 1e-4, i
     assert n_hh > 200 and n_fl > 2000 and bool(torch.isfinite(wc.qpos).all())

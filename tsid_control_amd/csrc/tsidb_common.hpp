@@ -56,7 +56,7 @@ enum {
   P_W_COM, P_KP_COM, P_KD_COM, P_W_POSTURE, P_HESS_REG, P_QUIRKS, P_NORMAL, P_CPOINTS = P_NORMAL + 3,
   P_KP_POSTURE = P_CPOINTS + 12, P_KD_POSTURE = P_KP_POSTURE + 20, P_TAU_MAX = P_KD_POSTURE + 20,
   P_V_MAX = P_TAU_MAX + 20, P_MAX_ITER = P_V_MAX + 20, P_SIM_ENABLED, P_CLOSED_LOOP, P_W_AM, P_KP_AM /*3*/,
-  P_REW_SIGMA = P_KP_AM + 3, P_REW_CTAU, P_DONE_HEIGHT, P_DONE_TILT, P_SELF_COLLISION, P_W_COP, P_SIM_FLOSS_SCALE, P_TSID_ARMATURE, P_FRICTION_COMP, P_COUNT = 128
+  P_REW_SIGMA = P_KP_AM + 3, P_REW_CTAU, P_DONE_HEIGHT, P_DONE_TILT, P_SELF_COLLISION, P_W_COP, P_SIM_FLOSS_SCALE, P_TSID_ARMATURE, P_FRICTION_COMP, P_PLANE_MESH, P_COUNT = 128
 };
 
 // Model constants in the arithmetic type of the path; one copy in HBM, read by every workgroup

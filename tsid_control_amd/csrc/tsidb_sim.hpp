@@ -1090,7 +1090,8 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
     __syncthreads();
   }
   int ncon = 0;
-  for (unsigned long long bm = cand_geoms; bm && ncon < MAXCON; bm &= bm - 1) {
+  const bool pm_rule = m.params[P_PLANE_MESH] != 0; // upstream's plane <-> mesh rule instead of "every neighbour in the margin"
+  for (unsigned long long bm = cand_geoms; bm; bm &= bm - 1) {
     const int g = __ffsll((long long)bm) - 1, b = m.geom_body[g];
     const T *Rb = L.R[b];
     // floor normal in the body frame; "z" below = signed distance to the floor
@@ -1107,7 +1108,7 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
     // the support vertex, then its hull-graph neighbours within the margin
     const int e0 = m.hull_eadr[best];
     int nnb = m.hull_eadr[best + 1] - e0;
-    nnb = nnb > WAVE - 1 ? WAVE - 1 : nnb;
+    if (nnb > WAVE - 1) { nnb = WAVE - 1; fail |= 16; }
     bool keep = false;
     T w[3] = {0, 0, 0}, wd = 0;
     int vid = best;
@@ -1120,7 +1121,17 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
       if (has_terr) wd -= terrain_h(L.terr, w[0] + Ow[0], w[1] + Ow[1]);
       keep = lane == 0 || wd <= margin;
     }
+    T cp[3] = {w[0] - T(0.5) * wd * fl.n[0], w[1] - T(0.5) * wd * fl.n[1], w[2] - T(0.5) * wd * fl.n[2]}; // contact position
+    if (pm_rule) {
+      // in graph order (= lane order): at most 3 more contacts, each at least 0.3 rbound from the FIRST one (lane 0's)
+      const T d3[3] = {cp[0] - rdlane(cp[0], 0), cp[1] - rdlane(cp[1], 0), cp[2] - rdlane(cp[2], 0)};
+      const T thr = T(0.3) * m.rbound[g][3];
+      const bool far = lane > 0 && keep && !(dot3(d3, d3) < thr * thr);
+      const unsigned long long fm = __ballot(far);
+      keep = lane == 0 || (far && __popcll(fm & ((1ull << lane) - 1ull)) < 3);
+    }
     const unsigned long long mask = __ballot(keep);
+    if (ncon + __popcll(mask) > MAXCON) fail |= 8; // a contact is dropped at the cap
     const int slot = ncon + __popcll(mask & ((1ull << lane) - 1ull));
     if (keep && slot < MAXCON) {
       const T dist = wd;
@@ -1129,7 +1140,7 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
       L.cvert[slot] = vid - v0;
       L.cdist[slot] = dist;
 #pragma unroll
-      for (int i = 0; i < 3; i++) L.cr[slot][i] = w[i] - T(0.5) * dist * fl.n[i];
+      for (int i = 0; i < 3; i++) L.cr[slot][i] = cp[i];
     }
     ncon += __popcll(mask);
     ncon = ncon > MAXCON ? MAXCON : ncon;
@@ -1152,7 +1163,7 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
     // broad phase, one lane per pair: sphere test, survivors compacted into a list; the box test then runs on the list
     // 64 entries at a time (once, at the end, for the v1 robot's ~30 survivors; the v0 robot has 1044 pairs)
     int nsph = 0, ncand = 0;
-    bool over = false;
+    bool over = false, over64 = false;
     auto box_pass = [&](int cnt) { // pcand[0, cnt) -> survivors appended to fcand, in pair order
       const int k = lane < cnt ? L.pcand[lane] : 0;
       const bool may = lane < cnt && boxes_may_touch(m, L, m.pair_a[k], m.pair_b[k], margin);
@@ -1179,7 +1190,7 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
     }
     __syncthreads();
     box_pass(nsph);
-    if (ncand > WAVE) { ncand = WAVE; over = true; }
+    if (ncand > WAVE) { ncand = WAVE; over64 = true; }
     __syncthreads();
     for (int ci = 0; ci < ncand; ci++) {
       const int k = L.fcand[ci];
@@ -1200,6 +1211,7 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
       ncon++;
     }
     if (over) fail |= 8;
+    if (over64) fail |= 32;
   }
 #endif
   __syncthreads();

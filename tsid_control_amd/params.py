@@ -41,6 +41,7 @@ P_W_COP = 123
 P_SIM_FLOSS_SCALE = 124
 P_TSID_ARMATURE = 125
 P_FRICTION_COMP = 126
+P_PLANE_MESH = 127
 P_COUNT = 128
 
 
@@ -94,6 +95,10 @@ def pack_params(conf, effort_limit, velocity_limit):
     p[P_SIM_FLOSS_SCALE] = getattr(conf, "sim_frictionloss_scale", 1.0)
     p[P_TSID_ARMATURE] = getattr(conf, "tsid_armature", 0.0)
     p[P_FRICTION_COMP] = getattr(conf, "friction_compensation", 0.0)
+    pm = getattr(conf, "sim_plane_mesh", "all")
+    if pm not in ("all", "mujoco"):
+        raise ValueError("conf.sim_plane_mesh must be 'all' or 'mujoco'")
+    p[P_PLANE_MESH] = 1.0 if pm == "mujoco" else 0.0
     if p[P_CLOSED_LOOP] and not p[P_SIM_ENABLED]:
         raise ValueError("closed_loop needs the sim stage (sim_enabled=True)")
     return p
