@@ -72,8 +72,8 @@ OrModel *or_model_load(const void *blob, size_t nbytes) {
   if (!OR_HAS_SIM) { /* TSID-only robot: no sim sections */
     if (e) { or_model_free(m); return NULL; }
     m->floss_scale = 1.0;
-  m->plane_mesh = 0;
-    m->plane_mesh = 0;
+  m->plane_mesh = 1; /* RobotConfig.sim_plane_mesh = "mujoco" */
+    m->plane_mesh = 1; /* RobotConfig.sim_plane_mesh = "mujoco" */
     m->foot_body[0] = m->foot_body[1] = -1;
     return m;
   }
@@ -120,7 +120,7 @@ OrModel *or_model_load(const void *blob, size_t nbytes) {
   for (int i = 0; i < OR_NV; i++) s += m->mj_dof_M0[i];
   m->meaninertia = s / OR_NV;
   m->floss_scale = 1.0;
-  m->plane_mesh = 0;
+  m->plane_mesh = 1; /* RobotConfig.sim_plane_mesh = "mujoco" */
   {
     int s2t[OR_NA];
     m->foot_body[0] = m->foot_body[1] = -1;

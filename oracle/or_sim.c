@@ -120,9 +120,12 @@ static void chol_solve(double L[NV][NV], int n, const double *b, double *x) {
 static int chol_rank1(double L[NV][NV], int n, double *x, double sigma) {
   for (int k = 0; k < n; k++) {
     if (x[k] == 0.0) continue;
-    const double r2 = L[k][k] * L[k][k] + sigma * x[k] * x[k];
-    if (!(r2 > 0)) return -1;
-    const double r = sqrt(r2), c = r / L[k][k], s = x[k] / L[k][k];
+    /* s = x_k / L_kk, c = sqrt(1 + sigma s^2) = the diagonal's growth factor.  A downdate that takes the pivot to (nearly)
+     * nothing - 1 - s^2 <= 1e-10: the row carried all but that fraction of the diagonal - has lost its digits to
+     * cancellation: rebuild instead (same rule on the device) */
+    const double s = x[k] / L[k][k], q = 1.0 + sigma * s * s;
+    if (!(q > 1e-10)) return -1;
+    const double c = sqrt(q), r = L[k][k] * c;
     L[k][k] = r;
     for (int i = k + 1; i < n; i++) {
       L[i][k] = (L[i][k] + sigma * s * x[i]) / c;

@@ -210,7 +210,7 @@ class Oracle:
         return dict(tau=tau, dv=dv, f=f, obs=obs, status=st, iters=it.value)
 
     # ---- sim
-    def sim_step(self, qpos, qvel, ctrl, qacc_ws, envp=None, terrain=None, self_collision=True, plane_mesh="all"):
+    def sim_step(self, qpos, qvel, ctrl, qacc_ws, envp=None, terrain=None, self_collision=True, plane_mesh="mujoco"):
         assert all(x.dtype == np.float64 for x in (qpos, qvel, qacc_ws))
         self.lib.or_model_set_plane_mesh.argtypes = [C.c_void_p, C.c_int]
         self.lib.or_model_set_plane_mesh(self.m, int(plane_mesh == "mujoco"))

@@ -24,7 +24,9 @@ def cases():
     mb = ModelBlob(None)
     orc = Oracle(mb.raw)
     out = []
-    for seed, over in ((0, {}), (1, {"reference_quirks": False}), (2, {"w_am": 1e-3}), (3, {"closed_loop": True})):
+    # (round 3: the default plane <-> mesh contact rule became "mujoco"; the last case keeps rounds 1-2's "all")
+    for seed, over in ((0, {}), (1, {"reference_quirks": False}), (2, {"w_am": 1e-3}), (3, {"closed_loop": True}),
+                       (0, {"sim_plane_mesh": "all"})):
         conf = RobotConfig()
         for k, v in over.items():
             setattr(conf, k, v)

@@ -1334,7 +1334,7 @@ def test_contact_caps_are_flagged(oracle):
     """silent caps are not silent: a robot lying on the floor makes more floor contacts than TSIDB_MAXCON - bit 8 of info[:, 3],
     on the device as in the oracle"""
     n = 4
-    wc = make(n, self_collision=True)
+    wc = make(n, self_collision=True, sim_plane_mesh="all")      # (every neighbour in the margin: the rule that can overflow)
     quats = torch.tensor([[0.7071068, 0.7071068, 0, 0], [0.7071068, 0, 0.7071068, 0], [0.5, 0.5, 0.5, 0.5], [1.0, 0, 0, 0]],
                          dtype=wc.dtype, device=wc.device)
     wc.qpos[:, 3:7] = quats
@@ -1343,7 +1343,7 @@ def test_contact_caps_are_flagged(oracle):
     wc.sim_step(teleport=False)
     flagged = 0
     for e in range(n):
-        r = oracle.sim_step(qpos[e], qvel[e], np.zeros(20), ws[e], self_collision=True)
+        r = oracle.sim_step(qpos[e], qvel[e], np.zeros(20), ws[e], self_collision=True, plane_mesh="all")
         assert r["flags"] == int(wc.info[e, 3]) & (8 | 16 | 32), e
         assert r["ncon"] == int(wc.ncon[e])
         flagged += int(bool(r["flags"] & 8))

@@ -189,7 +189,7 @@ def test_oracle_self_regression():
     import make_oracle_regression as gen
     want = json.loads((g / "oracle_regression.json").read_text())
     got = gen.cases()
-    assert len(want) == len(got) == 4
+    assert len(want) == len(got) == 5
     for w, c in zip(want, got):
         assert w["status"] == c["status"] and w["ncon"] == c["ncon"] and w["con_geom"] == c["con_geom"], w["seed"]
         for k in ("q", "v", "tau", "dv", "f", "qpos", "qvel", "obs"):

@@ -63,9 +63,11 @@ def test_resting_contact_balances_weight(oracle):
 
 def test_contact_indexing_is_deterministic(oracle):
     qpos = np.zeros(NQ); qpos[2] = 0.3319677531 - 0.0005; qpos[3] = 1.0
-    a = oracle.sim_step(qpos.copy(), np.zeros(NV), np.zeros(20), np.zeros(NV))
-    b = oracle.sim_step(qpos.copy(), np.zeros(NV), np.zeros(20), np.zeros(NV))
+    a = oracle.sim_step(qpos.copy(), np.zeros(NV), np.zeros(20), np.zeros(NV), plane_mesh="all")
+    b = oracle.sim_step(qpos.copy(), np.zeros(NV), np.zeros(20), np.zeros(NV), plane_mesh="all")
     assert a["ncon"] == b["ncon"] == 16
+    c = oracle.sim_step(qpos.copy(), np.zeros(NV), np.zeros(20), np.zeros(NV))    # the default rule: at most 4 per sole
+    assert c["ncon"] == 8 and set(c["con_vert"].tolist()) <= set(a["con_vert"].tolist())
     assert np.array_equal(a["con_geom"], b["con_geom"]) and np.array_equal(a["con_vert"], b["con_vert"])
     assert np.all(a["con_dist"] <= 0) and np.all(np.diff(a["con_geom"]) >= 0)
 

@@ -97,9 +97,10 @@ class RobotConfig:
                                # (4 for up to 1024 envs, else 1)
     self_collision = True      # sim stage collides the robot<->robot convex-hull pairs, as mj_step does (main.py:195);
     #                            False = floor contacts only (round-1 behaviour)
-    sim_plane_mesh = "all"     # sim stage, floor <-> hull contacts (main.py:195): "all" = the support vertex and every hull-graph
-    #                            neighbour of it within the margin; "mujoco" = upstream's plane-mesh rule as far as it is known
-    #                            here: at most 3 more, each >= 0.3 x the geom's bounding radius from the first
+    sim_plane_mesh = "mujoco"  # sim stage, floor <-> hull contacts (main.py:195).  "mujoco" = upstream's plane-mesh rule as far as it
+    #                            is known here (mujoco itself is not available): the support vertex, then in hull-graph order at most
+    #                            3 more of its neighbours within the margin, each >= 0.3 x the geom's bounding radius from the first;
+    #                            "all" = every neighbour within the margin (rounds 1-2: up to 30 contacts under one flat sole)
     w_cop = 0.0                # CoP force task of legacy/biped.py:79-80 (legacy/op3_conf.py:14 uses 0); 0 = off
     sim_frictionloss_scale = 1.0   # closed-loop knobs, neutral = the reference's models: scale of the sim's joint frictionloss
     tsid_armature = 0.0            #   (robot.xml:8), rotor inertia on the diagonal of TSID's M (the sim has 0.005, the URDF none),

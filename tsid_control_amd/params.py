@@ -95,7 +95,7 @@ def pack_params(conf, effort_limit, velocity_limit):
     p[P_SIM_FLOSS_SCALE] = getattr(conf, "sim_frictionloss_scale", 1.0)
     p[P_TSID_ARMATURE] = getattr(conf, "tsid_armature", 0.0)
     p[P_FRICTION_COMP] = getattr(conf, "friction_compensation", 0.0)
-    pm = getattr(conf, "sim_plane_mesh", "all")
+    pm = getattr(conf, "sim_plane_mesh", "mujoco")
     if pm not in ("all", "mujoco"):
         raise ValueError("conf.sim_plane_mesh must be 'all' or 'mujoco'")
     p[P_PLANE_MESH] = 1.0 if pm == "mujoco" else 0.0
