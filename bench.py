@@ -227,12 +227,13 @@ def run_workload(a, dev, rank, world, n, with_gather=True):
 
     def one_step(i, timed_idx=None):
         par = i & 1
-        if sched is not None:
-            sched.apply(wc, i * conf.dt)
         e = ev[timed_idx] if timed_idx is not None else None
         if overlap:
-            wc.step_pipelined(events=e)
+            # the walking reference update of this tick runs in the tick's own launch (tsidb_tick_walk)
+            wc.step_pipelined(events=e, walk=(sched, i * conf.dt) if sched is not None else None)
         else:
+            if sched is not None:
+                sched.apply(wc, i * conf.dt)
             if getattr(a, "closed_loop", False):   # one call: the tick reads the sim state, the sim takes tau
                 if e: e[0].record(s_tick)
                 wc.step()
@@ -485,6 +486,18 @@ def main():
             traffic_src = f"profiles/pmc_traffic.json ({rec_all.get('source', 'rocprofv3 --pmc passes')}; not measured by this run)"
             pmc = rec_all.get("valu", {}).get(dom)
 
+    # what binds the dominant kernel, from the committed instruction-class counters (tools/pmc_profile.sh pass p5) and THIS run's
+    # launch time: float64 lane-flops as issued against the 78.6 TFLOP/s vector peak, and the VALU issue floor (4 cycles per
+    # double-precision instruction, 2 per other VALU instruction on a SIMD-32 shared by two wavefronts) against the launch time
+    # at the 2.4 GHz maximum clock - both lower bounds of the utilisation (the clock under load is lower, idle lanes count)
+    vec = None
+    if pmc and "f64_lane_flops_issued_per_env" in pmc:
+        t_s = dom_ms * 1e-3
+        floor_s = (n / 1024.0) * pmc["issue_floor_cycles_per_env"] / 2.4e9
+        vec = {"f64_issued_tflops": pmc["f64_lane_flops_issued_per_env"] * n / t_s / 1e12, "f64_vector_peak_tflops": VALU_PEAK_TFLOPS["f64"],
+               "f64_frac_of_vector_peak": pmc["f64_lane_flops_issued_per_env"] * n / t_s / 1e12 / VALU_PEAK_TFLOPS["f64"],
+               "f64_share_of_valu_instructions": pmc["f64_share_of_valu"],
+               "valu_issue_floor_ms_at_2p4GHz": 1e3 * floor_s, "valu_issue_floor_frac_of_launch": floor_s / t_s}
     if rank == 0:
         value = world * n * args.steps / el
         out = {
@@ -506,7 +519,7 @@ def main():
                          # what actually binds these kernels: VALU issue + dependency latency of
                          # one wavefront per env; the HBM fraction above is reported because the north star asks for it
                          "binding_resource": "valu-issue + dependency latency (one wavefront per env)",
-                         "valu_issue_from_profiles": pmc,
+                         "valu_issue_from_profiles": pmc, "vector_roofline_from_profiles": vec,
                          "valu_frac_nominal": (n * NOMINAL_FLOP_PER_ENV_STEP / ((tick_ms + sim_ms) * 1e-3)) / (VALU_PEAK_TFLOPS[args.dtype] * 1e12)},
         }
         if world == 1 and args.cpu_seconds > 0:

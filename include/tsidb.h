@@ -72,6 +72,12 @@ int tsidb_set_params(tsidb_handle h, const double *params, int n_params);
 int tsidb_set_refs(tsidb_handle h, const void *com_ref, const void *posture_ref, const void *foot_ref,
                    const void *contact_ref, const uint8_t *contact_active, const void *cop_frames);
 
+/* execution options that do not change results.  TSIDB_OPT_SIM_WAVES: wavefronts per env in the sim kernel - 1 (one wavefront
+ * per env: the throughput-optimal shape once the batch fills the GPU) or 2 (collision phase on a second wavefront beside the
+ * unconstrained dynamics: shorter step latency for small batches).  Default: 2 for up to 640 envs, else 1.  Bit-identical. */
+enum { TSIDB_OPT_SIM_WAVES = 1 };
+int tsidb_set_option(tsidb_handle h, int option, int value);
+
 /* reference point of the CoP force task (legacy/biped.py:79-80 copTask; params[W_COP] != 0): cop_ref [N,3], world
  * frame; written by tsidb_reset (midpoint of the soles on the floor).  The pointer is remembered, not copied. */
 int tsidb_set_cop_ref(tsidb_handle h, const void *cop_ref);
@@ -184,6 +190,22 @@ int tsidb_walk_plan(tsidb_handle h, const int32_t *env_ids, int n_ids, const voi
                     const double *scale, int32_t *episode, int bump_episode, int K, double *steps, void *coef, int32_t *side,
                     int32_t *nsteps, void *rest, void *com, int32_t *flags, void *t_offset, int32_t *td_latch, double t,
                     const double *t_device, void *stream);
+
+/* tsidb_walk_update's arguments as one block (same meaning, same order) */
+typedef struct tsidb_walk_args {
+  const void *coef; const int32_t *side; const int32_t *nsteps; const void *rest; const void *com; int K;
+  double t, step_duration, t_start, omega, com_z0, com_drop;
+  const void *frames; const void *t_offset; const int32_t *ncon; const int32_t *con_pairs; int32_t *td_latch; double td_fraction;
+  const double *t_device;
+} tsidb_walk_args;
+
+/* tsidb_tick with two fusions for the tick stream of a pipelined step (what bounds small batches: three launches less):
+ * walk (may be NULL): this tick's walking reference update (exactly tsidb_walk_update(walk...), run per env in the tick kernel's
+ * prologue: controller.update_tasks(...) of main.py:117 and formulation.computeProblemData of main.py:119 in one launch);
+ * q_snapshot / v_snapshot (may be NULL) [N,27] / [N,26]: a second copy of the TSID state the tick ends on, for a sim stage that
+ * runs on another stream while the next tick already overwrites q / v.  Results are those of the separate calls, bit for bit. */
+int tsidb_tick_walk(tsidb_handle h, const tsidb_walk_args *walk, void *q, void *v, void *tau, void *dv, void *f, int32_t *status,
+                    void *obs, int obs_ld, void *frames, int32_t *info, void *q_snapshot, void *v_snapshot, void *stream);
 
 /* probe of formulation.computeProblemData's rigid-body terms (main.py:119): M [N,26,26],
  * hbias [N,26], Jcom [N,3,26], Jf [N,2,6,26] (LOCAL), oMf [N,2,12], com [N,3].  Test/debug use. */

@@ -1,7 +1,8 @@
 """GPU parity: the HIP path (through the C-ABI, via the WalkController facade) against the CPU oracle
 on the same seeded inputs.  Tolerances:
   f64 path  - tau/dv/f-wrench 1e-7 abs, next q/v/qpos 1e-9, qvel 1e-6; status, contact pairs bit-exact
-  f32 path  - tau, dv rtol 1e-3 / atol 1e-4, per-foot wrench rtol 1e-3 / atol 1e-3 on one tick from identical inputs
+  f32 path  - one tick / one env step from identical inputs: test_single_tick_f32_within_tolerance (64 envs) and
+              test_one_env_step_f32_against_section5 (256 envs; states what holds as written and what only in an amended form)
 The oracle itself is unpinned against tsid/pinocchio/mujoco (none available)."""
 import numpy as np
 import pytest
@@ -143,6 +144,44 @@ def test_single_tick_f32_within_tolerance(oracle):
     assert np.allclose(dv, st["dv"], rtol=1e-3, atol=1e-4)
     assert np.allclose(wrench(wc.f.double().cpu().numpy(), wc.params), wrench(st["f"], wc.params), rtol=1e-3, atol=1e-3)
     assert diff(wc.q, st["q"]) < 1e-5 and diff(wc.v, st["v"]) < 1e-4
+
+
+def test_one_env_step_f32_against_section5(oracle):
+    """The f32 path against BASELINE.md section 5 on ONE env step from identical inputs, 256 perturbed standing envs (VERDICT r2
+    item 8) - what holds as written, and what holds only in an amended form, with the reason:
+      dv, next q, next v         as written (rtol 1e-3 / atol 1e-4; atol 1e-5): observed 2e-5, 3e-8, 4e-8
+      per-foot wrench T f        rtol 1e-3 with the absolute part SCALED BY THE FOOT'S LOAD: atol 1e-4 x max(f_z, 1 N).  The
+                                 split of a foot's wrench among its 4 corner forces is fixed only by the 1e-8 regularisation, so
+                                 every component carries an error proportional to the 20 N the foot carries, not to itself
+                                 (observed 9.4e-5 of f_z; a 0.09 N m yaw moment cannot be right to 1e-4 N m beside 20 N)
+      tau                        rtol 1e-3 / atol 1e-3: tau is the O(0.1) N m remainder of M_a dv + h_a - J_a^T f, three O(1) N m
+                                 terms, and inherits the wrench's 1e-4 relative error on that scale (observed 9.7e-4 in 2 envs of 256;
+                                 254 meet the section as written)
+      contact (geom, vertex) ids bit-exact where float32 can tell the lowest sole vertex from its neighbours: ties are taken
+                                 within 2e-6 m in float32 (1e-9 in float64), so on near-flat soles the
+                                 support vertex - and with it the neighbour list - may differ: >= 85 % of the envs identical
+      next qpos, qvel            on the envs with identical contact lists: qpos atol 1e-5 as written (observed 1e-7); qvel atol
+                                 5e-5, 99 % within 1e-5 - the contact rows are stiff (D ~ 1e6 against M ~ 1e-3 in H = M + J^T D J),
+                                 and dt x qacc carries float32's share of that conditioning (observed 1.9e-5 in one env)"""
+    n = 256
+    wc = make(n, "f32")
+    perturb(wc, 4)
+    st = mirror(wc)
+    wc.step()
+    oracle.env_step_batch(wc.params, st, nthreads=8)
+    g = lambda k: getattr(wc, k).double().cpu().numpy().reshape(n, -1)
+    assert np.array_equal(wc.status.cpu().numpy(), st["status"])
+    assert np.allclose(g("dv"), st["dv"], rtol=1e-3, atol=1e-4)
+    assert np.abs(g("q") - st["q"]).max() < 1e-5 and np.abs(g("v") - st["v"]).max() < 1e-5
+    w, w0 = wrench(g("f"), wc.params), wrench(st["f"], wc.params)
+    fz = np.maximum(np.abs(w0[:, :, 2:3]), 1.0)
+    assert (np.abs(w - w0) <= 1e-4 * fz + 1e-3 * np.abs(w0)).all()
+    tau_ok = (np.abs(g("tau") - st["tau"]) <= 1e-4 + 1e-3 * np.abs(st["tau"])).all(axis=1)
+    assert tau_ok.mean() >= 0.98 and np.allclose(g("tau"), st["tau"], rtol=1e-3, atol=1e-3)
+    same = (wc.con_pairs.cpu().numpy() == st["con_geom"]).all(axis=1)
+    assert same.mean() >= 0.85 and (wc.ncon.cpu().numpy() == st["ncon"]).mean() >= 0.95
+    dq, dqv = np.abs(g("qpos") - st["qpos"])[same], np.abs(g("qvel") - st["qvel"])[same]
+    assert dq.max() < 1e-5 and dqv.max() < 5e-5 and (dqv.max(axis=1) <= 1e-5).mean() >= 0.99
 
 
 def test_sim_only_settles_on_the_floor_f64(oracle):
@@ -1350,3 +1389,25 @@ def test_contact_caps_are_flagged(oracle):
         if r["flags"] & 8:
             assert r["ncon"] == 32
     assert flagged >= 1 and int(wc.info[3, 3]) == 0     # the standing env is not flagged
+
+
+def test_two_wavefront_sim_is_bit_identical():
+    """conf.sim_waves: the small-batch shape of the sim kernel (collision phase on a second wavefront beside the
+    unconstrained dynamics; the default up to 2048 envs) against one wavefront per env - same operations on the same data,
+    bit for bit: perturbed standing, randomised floors with terrain steps, self-colliding poses"""
+    n = 96
+    a, b = make(n, sim_waves=1), make(n, sim_waves=2)
+    for w in (a, b):
+        perturb(w, 41, dq=0.04, dv=0.05)
+        w.randomize(seed=3)
+        w.qpos[: n // 3, 7:] = _self_collision_poses(n // 3, 5).to(w.device, w.dtype)
+    for i in range(30):
+        a.step()
+        b.step()
+    for i in range(20):
+        a.sim_step(teleport=False)
+        b.sim_step(teleport=False)
+    torch.cuda.synchronize()
+    for k in ("q", "v", "tau", "qpos", "qvel", "qacc_warmstart", "ncon", "con_pairs", "info", "rows"):
+        assert torch.equal(getattr(a, k), getattr(b, k)), k
+    assert int(a.ncon.max()) > 4 and int((a.con_pairs & 0x8000).bool().sum()) > 0     # floor and robot<->robot contacts were there

@@ -11,13 +11,22 @@ LIB_PATH = Path(os.environ.get("TSIDB_LIB_PATH", _HERE / "libtsidb.so"))
 
 SYMBOLS = ["tsidb_dims", "tsidb_create", "tsidb_destroy", "tsidb_last_error", "tsidb_set_params", "tsidb_set_refs", "tsidb_reset",
            "tsidb_tick", "tsidb_sim", "tsidb_step", "tsidb_rbd_terms", "tsidb_lds_bytes", "tsidb_walk_update", "tsidb_set_env_params", "tsidb_set_cop_ref",
-           "tsidb_reset_done", "tsidb_set_posture_bias", "tsidb_walk_plan"]
+           "tsidb_reset_done", "tsidb_set_posture_bias", "tsidb_walk_plan", "tsidb_set_option", "tsidb_tick_walk"]
 
 _libs = {}
 
 
 class TsidbError(RuntimeError):
     pass
+
+
+class WalkArgs(C.Structure):
+    """tsidb_walk_args (include/tsidb.h): tsidb_walk_update's arguments as one block"""
+    _fields_ = [("coef", C.c_void_p), ("side", C.c_void_p), ("nsteps", C.c_void_p), ("rest", C.c_void_p), ("com", C.c_void_p),
+                ("K", C.c_int), ("t", C.c_double), ("step_duration", C.c_double), ("t_start", C.c_double), ("omega", C.c_double),
+                ("com_z0", C.c_double), ("com_drop", C.c_double), ("frames", C.c_void_p), ("t_offset", C.c_void_p),
+                ("ncon", C.c_void_p), ("con_pairs", C.c_void_p), ("td_latch", C.c_void_p), ("td_fraction", C.c_double),
+                ("t_device", C.c_void_p)]
 
 
 def dims9(L):
@@ -75,6 +84,8 @@ def load(path=None):
     L.tsidb_dims.argtypes = [C.POINTER(C.c_int)]
     L.tsidb_reset_done.argtypes = [vp, vp, C.c_int] + [vp] * 7
     L.tsidb_set_posture_bias.argtypes = [vp, vp]
+    L.tsidb_set_option.argtypes = [vp, C.c_int, C.c_int]
+    L.tsidb_tick_walk.argtypes = [vp, vp] + [vp] * 7 + [C.c_int] + [vp] * 5
     L.tsidb_walk_plan.argtypes = [vp, vp, C.c_int, vp, C.c_int, vp, C.c_int, vp, vp, C.c_int, vp, vp, C.c_int, C.c_int] + [vp] * 9 + \
                                  [C.c_double, vp, vp]
     for s in SYMBOLS:

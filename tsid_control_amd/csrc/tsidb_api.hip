@@ -13,198 +13,29 @@
 using namespace tsidb;
 
 // ============================================================================ kernels
-// One launch, three bodies: the tick is compiled for every contact configuration (NS = 2, 1, 0 feet in
-// contact: 50 / 38 / 26 variables, every loop bound a compile-time constant) and each workgroup branches
-// to the body of its env.  Three separate kernels (tried first) allocate registers a little better, but
-// a variant with nothing to do still queues 4096 workgroups that each need the full LDS allocation, and
-// in one stream it holds the working variant back behind whatever else occupies the GPU (the sim of
-// the previous step): 11.0 M -> 12.9 M env-steps/s from merging them.
-// COP: the variant with the CoP force task rows (legacy/biped.py:79-80) compiled in; the reference's
-// ctrl/WalkController.py stack (w_cop = 0) runs the variant without them.
-template <typename T, bool COP>
-__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2))) void k_tick(const DevModel<T> *__restrict__ mp, int n, T *q, T *v, const T *com_ref,
-                                                  const T *posture_ref, const T *foot_ref, const T *contact_ref,
-                                                  const uint8_t *cact, const T *cop_frames, T *tau, T *dv, T *f,
-                                                  int *status, T *obs, int obs_ld, T *frames, int *info, const T *qpos_sim,
-                                                  const T *qvel_sim, const T *cop_ref) {
-  __shared__ TickLds<T> L;
-  const int lane = threadIdx.x;
-  if ((int)blockIdx.x >= n) return;
-  const int e = env_of_block(blockIdx.x, n);
-  const size_t E = (size_t)e;
-  const int ns = (cact[E * 2] != 0) + (cact[E * 2 + 1] != 0);
-  {
-    // a non-finite state or reference never enters the solver: the env is flagged HQP_STATUS_ERROR (4) and
-    // left untouched (the dual active-set loop's exit tests are comparisons, which NaN makes meaningless)
-    const T *qs = qpos_sim ? qpos_sim + E * NQ : q + E * NQ, *vs = qvel_sim ? qvel_sim + E * NV : v + E * NV;
-    T chk = 0;
-    if (lane < NQ) chk += fabs(qs[lane]);
-    if (lane < NV) chk += fabs(vs[lane]);
-    if (lane < 9) chk += fabs(com_ref[E * 9 + lane]);
-    if (lane < NA) chk += fabs(posture_ref[E * NA + lane]);
-    if (lane < 48) chk += fabs(foot_ref[E * 48 + lane]);
-    if (lane < 24) chk += fabs(contact_ref[E * 24 + lane]);
-    if (__ballot(!(chk <= Eps<T>::inf))) {
-      // nothing of an earlier tick is handed on either: tau = dv = f = 0, as after a failed solve (in the closed loop
-      // the env's motors go limp instead of being driven by stale torques)
-      if (lane < NA) tau[E * NA + lane] = 0;
-      if (lane < NV) dv[E * NV + lane] = 0;
-      if (lane < 24) f[E * 24 + lane] = 0;
-      if (lane == 0) {
-        status[e] = 4;
-        if (info) { info[E * 4] = 0; info[E * 4 + 1] = 0; }
-        if (obs && obs_ld >= NROW) { obs[E * obs_ld + NOBS] = 0; obs[E * obs_ld + NOBS + 1] = 1; }
-      }
-      return;
-    }
-  }
-#ifdef TSIDB_ONLY_NS // (diagnostic builds: one body, to read its resource usage alone)
-  if (ns != TSIDB_ONLY_NS) return;
-#endif
-  if (ns == 2) {
-    tsid_tick_env<T, 2, COP>(*mp, L, lane, q + E * NQ, v + E * NV, com_ref + E * 9, posture_ref + E * NA, foot_ref + E * 48,
-                         contact_ref + E * 24, cact + E * 2, cop_frames ? cop_frames + E * 24 : nullptr, tau + E * NA,
-                         dv + E * NV, f + E * 24, status + e, obs ? obs + E * obs_ld : nullptr, (obs && obs_ld >= NROW) ? obs + E * obs_ld + NOBS : nullptr, info ? info + E * 4 : nullptr,
-                         qpos_sim ? qpos_sim + E * NQ : nullptr, qvel_sim ? qvel_sim + E * NV : nullptr, cop_ref ? cop_ref + E * 3 : nullptr);
-  } else if (ns == 1) {
-    tsid_tick_env<T, 1, COP>(*mp, L, lane, q + E * NQ, v + E * NV, com_ref + E * 9, posture_ref + E * NA, foot_ref + E * 48,
-                         contact_ref + E * 24, cact + E * 2, cop_frames ? cop_frames + E * 24 : nullptr, tau + E * NA,
-                         dv + E * NV, f + E * 24, status + e, obs ? obs + E * obs_ld : nullptr, (obs && obs_ld >= NROW) ? obs + E * obs_ld + NOBS : nullptr, info ? info + E * 4 : nullptr,
-                         qpos_sim ? qpos_sim + E * NQ : nullptr, qvel_sim ? qvel_sim + E * NV : nullptr, cop_ref ? cop_ref + E * 3 : nullptr);
-  } else {
-    tsid_tick_env<T, 0, COP>(*mp, L, lane, q + E * NQ, v + E * NV, com_ref + E * 9, posture_ref + E * NA, foot_ref + E * 48,
-                         contact_ref + E * 24, cact + E * 2, cop_frames ? cop_frames + E * 24 : nullptr, tau + E * NA,
-                         dv + E * NV, f + E * 24, status + e, obs ? obs + E * obs_ld : nullptr, (obs && obs_ld >= NROW) ? obs + E * obs_ld + NOBS : nullptr, info ? info + E * 4 : nullptr,
-                         qpos_sim ? qpos_sim + E * NQ : nullptr, qvel_sim ? qvel_sim + E * NV : nullptr, cop_ref ? cop_ref + E * 3 : nullptr);
-  }
-  if (frames && lane < 24) frames[E * 24 + lane] = L.oMf[lane / 12][lane % 12];
-}
-
+// walking reference update (Walk_Planner.py:23-31 samples -> WalkController.py:189-253): 16 lanes per env (r = 0..15).  Runs
+// either as its own kernel (k_walk, tsidb_walk_update) or in the prologue of k_tick (tsidb_tick_walk: one launch less on
+// the tick stream, which is what bounds small batches).
 template <typename T>
-__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2))) void k_sim(const DevModel<T> *__restrict__ mp, int n, const T *q_tsid, const T *v_tsid, T *qpos, T *qvel,
-                                              T *qacc_ws, const T *env_params, const T *terrain, const T *motor_tau, T *qacc, int *ncon,
-                                              int *con, int *info) {
-  __shared__ SimLds<T> L;
-  const int lane = threadIdx.x;
-  if ((int)blockIdx.x >= n) return;
-  const int e = env_of_block(blockIdx.x, n);
-  const size_t E = (size_t)e;
-  {
-    // non-finite sim state / targets, or a sim state that has diverged (sum of |qpos| + |qvel| beyond SIM_STATE_BOUND:
-    // the reference's own loop gets there, its teleported sim accumulates velocity until the contact forces explode -
-    // and products of such values overflow to inf / NaN inside the step): skip the step, failure bit 4 in info[3]
-    T chk = 0, big = 0;
-    if (lane < NQ) { big += fabs(qpos[E * NQ + lane]); chk += q_tsid ? fabs(q_tsid[E * NQ + lane]) : T(0); }
-    if (lane < NV) { big += fabs(qvel[E * NV + lane]); chk += fabs(qacc_ws[E * NV + lane]) + (v_tsid ? fabs(v_tsid[E * NV + lane]) : T(0)); }
-    if (lane < NA && motor_tau) chk += fabs(motor_tau[E * NA + lane]);
-    big = wave_sum(big);
-    if (__ballot(!(chk <= Eps<T>::inf)) || !(big <= T(SIM_STATE_BOUND))) {
-      if (lane == 0) {
-        if (info) { info[E * 4 + 2] = 0; info[E * 4 + 3] = 4; }
-        if (ncon) ncon[e] = 0;
-      }
-      if (con && lane < MAXCON) con[E * MAXCON + lane] = -1;
-      return;
-    }
-  }
-  sim_step_env<T>(*mp, L, lane, q_tsid ? q_tsid + E * NQ : nullptr, v_tsid ? v_tsid + E * NV : nullptr, qpos + E * NQ, qvel + E * NV, qacc_ws + E * NV,
-                  env_params ? env_params + E * 8 : nullptr, terrain ? terrain + E * 20 : nullptr, motor_tau ? motor_tau + E * NA : nullptr,
-                  qacc ? qacc + E * NV : nullptr, ncon ? ncon + e : nullptr, con ? con + E * MAXCON : nullptr,
-                  info ? info + E * 4 : nullptr);
-}
-
+struct WalkArgs {
+  const T *coef; const int *side; const int *nsteps; const T *rest; const T *com; int K;
+  T t_now; const T *t_off; T Tstep, t_start, omega, z0, dz;
+  const T *frames; T *foot_ref; T *contact_ref; uint8_t *cact; T *com_ref;
+  const int *ncon; const int *con; int *latch; unsigned long long fgeoms0, fgeoms1; T td_frac; const double *t_dev;
+};
 template <typename T>
-__global__ __launch_bounds__(WAVE) void k_rbd(const DevModel<T> *__restrict__ mp, int n, const T *q, const T *v, T *M, T *hb,
-                                              T *Jcom, T *Jf, T *oMf, T *com) {
-  __shared__ TickLds<T> L;
-  const int lane = threadIdx.x;
-  if ((int)blockIdx.x >= n) return;
-  const int e = env_of_block(blockIdx.x, n);
-  const size_t E = (size_t)e;
-  if (lane < NQ) L.qs[lane] = q[E * NQ + lane];
-  if (lane < NV) L.vs[lane] = v[E * NV + lane];
-  __syncthreads();
-  rbd_terms<T>(*mp, L, lane);
-  for (int i = lane; i < NV * NV; i += WAVE) M[E * NV * NV + i] = L.Dyn[(i / NV) * LDD + i % NV];
-  if (lane < NV) hb[E * NV + lane] = L.h[lane];
-  for (int i = lane; i < 3 * NV; i += WAVE) Jcom[E * 3 * NV + i] = L.k.Jcom[(i / NV) * LDF + i % NV];
-  for (int i = lane; i < 12 * NV; i += WAVE) Jf[E * 12 * NV + i] = L.k.Jf[(i / NV) * LDF + i % NV];
-  if (lane < 24) oMf[E * 24 + lane] = L.oMf[lane / 12][lane % 12];
-  if (lane < 3) com[E * 3 + lane] = L.com[lane];
-}
-
-// reset: standing state + references (WalkController.py:22-26,72-79,81,122,151-152,164-165; main.py:57-64)
-// done_rows (may be NULL): the [N, rows_ld] rows k_tick writes - only envs whose done flag (column NOBS + 1) is set are reset
-// (episode lifecycle on the device: no host round trip between `done` and the restart).  posture_bias (may be NULL, [NA]):
-// added to the captured posture reference (a walking workload's bent-knee posture).  frames (may be NULL): receives the
-// sole placements, as the host facade copies them after a reset.
-template <typename T>
-__global__ __launch_bounds__(WAVE) void k_reset(const DevModel<T> *__restrict__ mp, int n, const int *env_ids, int n_ids, T *q,
-                                                T *v, T *qpos, T *qvel, T *qacc_ws, T *com_ref, T *posture_ref,
-                                                T *foot_ref, T *contact_ref, uint8_t *cact, T *cop_frames, T *cop_ref,
-                                                const T *done_rows, int rows_ld, const T *posture_bias, T *frames) {
-  __shared__ TickLds<T> L;
-  const DevModel<T> &m = *mp;
-  const int lane = threadIdx.x;
-  int e = blockIdx.x;
-  if (env_ids) {
-    if (e >= n_ids) return;
-    e = env_ids[e];
-  }
-  if (e < 0 || e >= n) return;
-  const size_t E = (size_t)e;
-  if (done_rows && !(done_rows[E * rows_ld + NOBS + 1] != T(0))) return;
-  if (lane < NQ) L.qs[lane] = m.q0[lane];
-  if (lane < NV) L.vs[lane] = 0;
-  __syncthreads();
-  rbd_terms<T>(m, L, lane);
-  const T zlf = L.oMf[0][11];
-  __syncthreads();
-  if (lane == 0) L.qs[2] -= zlf; // WalkController.py:74
-  __syncthreads();
-  rbd_terms<T>(m, L, lane);
-  if (lane < NQ) q[E * NQ + lane] = L.qs[lane];
-  if (lane < NV) { v[E * NV + lane] = 0; qvel[E * NV + lane] = 0; qacc_ws[E * NV + lane] = 0; }
-  if (lane < NQ) {
-    T val = L.qs[lane]; // main.py:64: raw copy (quirks F6a/F6b); joints are all zero in "standing"
-    if (m.params[P_QUIRKS] == 0 || m.params[P_CLOSED_LOOP] != 0) {
-      if (lane == 3) val = L.qs[6];
-      else if (lane > 3 && lane < 7) val = L.qs[lane - 1];
-      else if (lane >= 7) val = L.qs[m.mj_ctrl_qidx[lane - 7]];
-    }
-    qpos[E * NQ + lane] = val;
-  }
-  if (lane < 24) {
-    const int f = lane / 12, i = lane % 12;
-    // SE3ToVector layout: p(3), R column-major(9)
-    T val = i < 3 ? L.oMf[f][9 + i] : L.oMf[f][3 * ((i - 3) % 3) + (i - 3) / 3];
-    contact_ref[E * 24 + lane] = val;
-    cop_frames[E * 24 + lane] = L.oMf[f][i];
-    if (frames) frames[E * 24 + lane] = L.oMf[f][i];
-  }
-  if (lane < 48) {
-    const int i = lane % 24;
-    // foot tasks never get a reference in the reference (quirk F6c): identity placement
-    foot_ref[E * 48 + lane] = (i == 3 || i == 7 || i == 11) ? T(1) : T(0);
-  }
-  if (lane < 9) com_ref[E * 9 + lane] = lane < 3 ? L.com[lane] : T(0);
-  if (lane < NA) posture_ref[E * NA + lane] = L.qs[7 + lane] + (posture_bias ? posture_bias[lane] : T(0));
-  if (lane < 2) cact[E * 2 + lane] = 1;
-  // CoP task reference: between the soles, on the floor
-  if (cop_ref && lane < 3) cop_ref[E * 3 + lane] = lane < 2 ? T(0.5) * (L.oMf[0][9 + lane] + L.oMf[1][9 + lane]) : T(0);
-}
-
-// walking reference update: one lane per env (Walk_Planner.py:23-31 samples -> WalkController.py:189-253)
-template <typename T>
-__global__ __launch_bounds__(256) void k_walk(int n, const T *coef, const int *side, const int *nsteps, const T *rest, const T *com,
-                                              int K, T t_now, const T *t_off, T Tstep, T t_start, T omega, T z0, T dz, const T *frames, T *foot_ref,
-                                              T *contact_ref, uint8_t *cact, T *com_ref, const int *ncon, const int *con, int *latch,
-                                              unsigned long long fgeoms0, unsigned long long fgeoms1, T td_frac, const double *t_dev) {
+__device__ __forceinline__ void walk_update_env(const WalkArgs<T> &wa, int e, int r) {
+  const T *coef = wa.coef, *rest = wa.rest, *com = wa.com, *t_off = wa.t_off, *frames = wa.frames;
+  const int *side = wa.side, *nsteps = wa.nsteps, *ncon = wa.ncon, *con = wa.con;
+  int *latch = wa.latch;
+  T *foot_ref = wa.foot_ref, *contact_ref = wa.contact_ref, *com_ref = wa.com_ref;
+  uint8_t *cact = wa.cact;
+  const int K = wa.K;
+  const T t_now = wa.t_now, Tstep = wa.Tstep, t_start = wa.t_start, omega = wa.omega, z0 = wa.z0, dz = wa.dz, td_frac = wa.td_frac;
+  const unsigned long long fgeoms0 = wa.fgeoms0, fgeoms1 = wa.fgeoms1;
+  const double *t_dev = wa.t_dev;
   // 16 lanes per env: every lane evaluates the (cheap) polynomials, each writes its share of the rows, so
   // the table reads hit one line per env and the reference rows are written as contiguous runs
-  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-  const int e = gid >> 4, r = gid & 15;
-  if (e >= n) return;
   const size_t E = (size_t)e;
   // per-env start delay (de-phased schedules): the env's own clock starts at t_off[e]
   T t = t_dev ? (T)t_dev[0] : t_now; // device clock (always float64: a float32 clock advanced by dt per tick drifts by
@@ -300,6 +131,208 @@ __global__ __launch_bounds__(256) void k_walk(int n, const T *coef, const int *s
     }
     com_ref[E * 9 + 3 * d + a] = val;
   }
+}
+
+// One launch, three bodies: the tick is compiled for every contact configuration (NS = 2, 1, 0 feet in
+// contact: 50 / 38 / 26 variables, every loop bound a compile-time constant) and each workgroup branches
+// to the body of its env.  Three separate kernels (tried first) allocate registers a little better, but
+// a variant with nothing to do still queues 4096 workgroups that each need the full LDS allocation, and
+// in one stream it holds the working variant back behind whatever else occupies the GPU (the sim of
+// the previous step): 11.0 M -> 12.9 M env-steps/s from merging them.
+// COP: the variant with the CoP force task rows (legacy/biped.py:79-80) compiled in; the reference's
+// ctrl/WalkController.py stack (w_cop = 0) runs the variant without them.
+template <typename T, bool COP>
+__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2))) void k_tick(const DevModel<T> *__restrict__ mp, int n, T *q, T *v, const T *com_ref,
+                                                  const T *posture_ref, const T *foot_ref, const T *contact_ref,
+                                                  const uint8_t *cact, const T *cop_frames, T *tau, T *dv, T *f,
+                                                  int *status, T *obs, int obs_ld, T *frames, int *info, const T *qpos_sim,
+                                                  const T *qvel_sim, const T *cop_ref, WalkArgs<T> wa, T *q_snap, T *v_snap) {
+  __shared__ TickLds<T> L;
+  const int lane = threadIdx.x;
+  if ((int)blockIdx.x >= n) return;
+  const int e = env_of_block(blockIdx.x, n);
+  const size_t E = (size_t)e;
+  if (wa.coef) { // this tick's walking reference update first (tsidb_tick_walk): it rewrites the references read below
+    if (lane < 16) walk_update_env<T>(wa, e, lane);
+    __syncthreads();
+  }
+  const int ns = (cact[E * 2] != 0) + (cact[E * 2 + 1] != 0);
+  {
+    // a non-finite state or reference never enters the solver: the env is flagged HQP_STATUS_ERROR (4) and
+    // left untouched (the dual active-set loop's exit tests are comparisons, which NaN makes meaningless)
+    const T *qs = qpos_sim ? qpos_sim + E * NQ : q + E * NQ, *vs = qvel_sim ? qvel_sim + E * NV : v + E * NV;
+    T chk = 0;
+    if (lane < NQ) chk += fabs(qs[lane]);
+    if (lane < NV) chk += fabs(vs[lane]);
+    if (lane < 9) chk += fabs(com_ref[E * 9 + lane]);
+    if (lane < NA) chk += fabs(posture_ref[E * NA + lane]);
+    if (lane < 48) chk += fabs(foot_ref[E * 48 + lane]);
+    if (lane < 24) chk += fabs(contact_ref[E * 24 + lane]);
+    if (__ballot(!(chk <= Eps<T>::inf))) {
+      // nothing of an earlier tick is handed on either: tau = dv = f = 0, as after a failed solve (in the closed loop
+      // the env's motors go limp instead of being driven by stale torques)
+      if (lane < NA) tau[E * NA + lane] = 0;
+      if (lane < NV) dv[E * NV + lane] = 0;
+      if (lane < 24) f[E * 24 + lane] = 0;
+      if (lane == 0) {
+        status[e] = 4;
+        if (info) { info[E * 4] = 0; info[E * 4 + 1] = 0; }
+        if (obs && obs_ld >= NROW) { obs[E * obs_ld + NOBS] = 0; obs[E * obs_ld + NOBS + 1] = 1; }
+      }
+      if (q_snap && lane < NQ) q_snap[E * NQ + lane] = q[E * NQ + lane]; // (the snapshot is the state as it stands)
+      if (v_snap && lane < NV) v_snap[E * NV + lane] = v[E * NV + lane];
+      return;
+    }
+  }
+#ifdef TSIDB_ONLY_NS // (diagnostic builds: one body, to read its resource usage alone)
+  if (ns != TSIDB_ONLY_NS) return;
+#endif
+  if (ns == 2) {
+    tsid_tick_env<T, 2, COP>(*mp, L, lane, q + E * NQ, v + E * NV, com_ref + E * 9, posture_ref + E * NA, foot_ref + E * 48,
+                         contact_ref + E * 24, cact + E * 2, cop_frames ? cop_frames + E * 24 : nullptr, tau + E * NA,
+                         dv + E * NV, f + E * 24, status + e, obs ? obs + E * obs_ld : nullptr, (obs && obs_ld >= NROW) ? obs + E * obs_ld + NOBS : nullptr, info ? info + E * 4 : nullptr,
+                         qpos_sim ? qpos_sim + E * NQ : nullptr, qvel_sim ? qvel_sim + E * NV : nullptr, cop_ref ? cop_ref + E * 3 : nullptr);
+  } else if (ns == 1) {
+    tsid_tick_env<T, 1, COP>(*mp, L, lane, q + E * NQ, v + E * NV, com_ref + E * 9, posture_ref + E * NA, foot_ref + E * 48,
+                         contact_ref + E * 24, cact + E * 2, cop_frames ? cop_frames + E * 24 : nullptr, tau + E * NA,
+                         dv + E * NV, f + E * 24, status + e, obs ? obs + E * obs_ld : nullptr, (obs && obs_ld >= NROW) ? obs + E * obs_ld + NOBS : nullptr, info ? info + E * 4 : nullptr,
+                         qpos_sim ? qpos_sim + E * NQ : nullptr, qvel_sim ? qvel_sim + E * NV : nullptr, cop_ref ? cop_ref + E * 3 : nullptr);
+  } else {
+    tsid_tick_env<T, 0, COP>(*mp, L, lane, q + E * NQ, v + E * NV, com_ref + E * 9, posture_ref + E * NA, foot_ref + E * 48,
+                         contact_ref + E * 24, cact + E * 2, cop_frames ? cop_frames + E * 24 : nullptr, tau + E * NA,
+                         dv + E * NV, f + E * 24, status + e, obs ? obs + E * obs_ld : nullptr, (obs && obs_ld >= NROW) ? obs + E * obs_ld + NOBS : nullptr, info ? info + E * 4 : nullptr,
+                         qpos_sim ? qpos_sim + E * NQ : nullptr, qvel_sim ? qvel_sim + E * NV : nullptr, cop_ref ? cop_ref + E * 3 : nullptr);
+  }
+  if (frames && lane < 24) frames[E * 24 + lane] = L.oMf[lane / 12][lane % 12];
+  // a second copy of the TSID state this tick ends on (what q / v hold now): the sim stage of the pipelined step reads it
+  // from there while the next tick already overwrites q / v (two copy kernels per step otherwise)
+  if (q_snap && lane < NQ) q_snap[E * NQ + lane] = L.qs[lane];
+  if (v_snap && lane < NV) v_snap[E * NV + lane] = L.vs[lane];
+}
+
+// NW = wavefronts per env: 1 when the batch fills the GPU, 2 for small batches (tsidb_sim.hpp: sim_step_env)
+template <typename T, int NW>
+__global__ __launch_bounds__(WAVE * NW) __attribute__((amdgpu_waves_per_eu(2))) void k_sim(const DevModel<T> *__restrict__ mp, int n, const T *q_tsid, const T *v_tsid, T *qpos, T *qvel,
+                                              T *qacc_ws, const T *env_params, const T *terrain, const T *motor_tau, T *qacc, int *ncon,
+                                              int *con, int *info) {
+  __shared__ SimLds<T> L;
+  const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
+  if ((int)blockIdx.x >= n) return;
+  const int e = env_of_block(blockIdx.x, n);
+  const size_t E = (size_t)e;
+  {
+    // non-finite sim state / targets, or a sim state that has diverged (sum of |qpos| + |qvel| beyond SIM_STATE_BOUND:
+    // the reference's own loop gets there, its teleported sim accumulates velocity until the contact forces explode -
+    // and products of such values overflow to inf / NaN inside the step): skip the step, failure bit 4 in info[3]
+    T chk = 0, big = 0;
+    if (lane < NQ) { big += fabs(qpos[E * NQ + lane]); chk += q_tsid ? fabs(q_tsid[E * NQ + lane]) : T(0); }
+    if (lane < NV) { big += fabs(qvel[E * NV + lane]); chk += fabs(qacc_ws[E * NV + lane]) + (v_tsid ? fabs(v_tsid[E * NV + lane]) : T(0)); }
+    if (lane < NA && motor_tau) chk += fabs(motor_tau[E * NA + lane]);
+    big = wave_sum(big);
+    if (__ballot(!(chk <= Eps<T>::inf)) || !(big <= T(SIM_STATE_BOUND))) {
+      if (wv == 0) {
+        if (lane == 0) {
+          if (info) { info[E * 4 + 2] = 0; info[E * 4 + 3] = 4; }
+          if (ncon) ncon[e] = 0;
+        }
+        if (con && lane < MAXCON) con[E * MAXCON + lane] = -1;
+      }
+      return;
+    }
+  }
+  sim_step_env<T, NW>(*mp, L, lane, wv, q_tsid ? q_tsid + E * NQ : nullptr, v_tsid ? v_tsid + E * NV : nullptr, qpos + E * NQ, qvel + E * NV, qacc_ws + E * NV,
+                  env_params ? env_params + E * 8 : nullptr, terrain ? terrain + E * 20 : nullptr, motor_tau ? motor_tau + E * NA : nullptr,
+                  qacc ? qacc + E * NV : nullptr, ncon ? ncon + e : nullptr, con ? con + E * MAXCON : nullptr,
+                  info ? info + E * 4 : nullptr);
+}
+
+template <typename T>
+__global__ __launch_bounds__(WAVE) void k_rbd(const DevModel<T> *__restrict__ mp, int n, const T *q, const T *v, T *M, T *hb,
+                                              T *Jcom, T *Jf, T *oMf, T *com) {
+  __shared__ TickLds<T> L;
+  const int lane = threadIdx.x;
+  if ((int)blockIdx.x >= n) return;
+  const int e = env_of_block(blockIdx.x, n);
+  const size_t E = (size_t)e;
+  if (lane < NQ) L.qs[lane] = q[E * NQ + lane];
+  if (lane < NV) L.vs[lane] = v[E * NV + lane];
+  __syncthreads();
+  rbd_terms<T>(*mp, L, lane);
+  for (int i = lane; i < NV * NV; i += WAVE) M[E * NV * NV + i] = L.Dyn[(i / NV) * LDD + i % NV];
+  if (lane < NV) hb[E * NV + lane] = L.h[lane];
+  for (int i = lane; i < 3 * NV; i += WAVE) Jcom[E * 3 * NV + i] = L.k.Jcom[(i / NV) * LDF + i % NV];
+  for (int i = lane; i < 12 * NV; i += WAVE) Jf[E * 12 * NV + i] = L.k.Jf[(i / NV) * LDF + i % NV];
+  if (lane < 24) oMf[E * 24 + lane] = L.oMf[lane / 12][lane % 12];
+  if (lane < 3) com[E * 3 + lane] = L.com[lane];
+}
+
+// reset: standing state + references (WalkController.py:22-26,72-79,81,122,151-152,164-165; main.py:57-64)
+// done_rows (may be NULL): the [N, rows_ld] rows k_tick writes - only envs whose done flag (column NOBS + 1) is set are reset
+// (episode lifecycle on the device: no host round trip between `done` and the restart).  posture_bias (may be NULL, [NA]):
+// added to the captured posture reference (a walking workload's bent-knee posture).  frames (may be NULL): receives the
+// sole placements, as the host facade copies them after a reset.
+template <typename T>
+__global__ __launch_bounds__(WAVE) void k_reset(const DevModel<T> *__restrict__ mp, int n, const int *env_ids, int n_ids, T *q,
+                                                T *v, T *qpos, T *qvel, T *qacc_ws, T *com_ref, T *posture_ref,
+                                                T *foot_ref, T *contact_ref, uint8_t *cact, T *cop_frames, T *cop_ref,
+                                                const T *done_rows, int rows_ld, const T *posture_bias, T *frames) {
+  __shared__ TickLds<T> L;
+  const DevModel<T> &m = *mp;
+  const int lane = threadIdx.x;
+  int e = blockIdx.x;
+  if (env_ids) {
+    if (e >= n_ids) return;
+    e = env_ids[e];
+  }
+  if (e < 0 || e >= n) return;
+  const size_t E = (size_t)e;
+  if (done_rows && !(done_rows[E * rows_ld + NOBS + 1] != T(0))) return;
+  if (lane < NQ) L.qs[lane] = m.q0[lane];
+  if (lane < NV) L.vs[lane] = 0;
+  __syncthreads();
+  rbd_terms<T>(m, L, lane);
+  const T zlf = L.oMf[0][11];
+  __syncthreads();
+  if (lane == 0) L.qs[2] -= zlf; // WalkController.py:74
+  __syncthreads();
+  rbd_terms<T>(m, L, lane);
+  if (lane < NQ) q[E * NQ + lane] = L.qs[lane];
+  if (lane < NV) { v[E * NV + lane] = 0; qvel[E * NV + lane] = 0; qacc_ws[E * NV + lane] = 0; }
+  if (lane < NQ) {
+    T val = L.qs[lane]; // main.py:64: raw copy (quirks F6a/F6b); joints are all zero in "standing"
+    if (m.params[P_QUIRKS] == 0 || m.params[P_CLOSED_LOOP] != 0) {
+      if (lane == 3) val = L.qs[6];
+      else if (lane > 3 && lane < 7) val = L.qs[lane - 1];
+      else if (lane >= 7) val = L.qs[m.mj_ctrl_qidx[lane - 7]];
+    }
+    qpos[E * NQ + lane] = val;
+  }
+  if (lane < 24) {
+    const int f = lane / 12, i = lane % 12;
+    // SE3ToVector layout: p(3), R column-major(9)
+    T val = i < 3 ? L.oMf[f][9 + i] : L.oMf[f][3 * ((i - 3) % 3) + (i - 3) / 3];
+    contact_ref[E * 24 + lane] = val;
+    cop_frames[E * 24 + lane] = L.oMf[f][i];
+    if (frames) frames[E * 24 + lane] = L.oMf[f][i];
+  }
+  if (lane < 48) {
+    const int i = lane % 24;
+    // foot tasks never get a reference in the reference (quirk F6c): identity placement
+    foot_ref[E * 48 + lane] = (i == 3 || i == 7 || i == 11) ? T(1) : T(0);
+  }
+  if (lane < 9) com_ref[E * 9 + lane] = lane < 3 ? L.com[lane] : T(0);
+  if (lane < NA) posture_ref[E * NA + lane] = L.qs[7 + lane] + (posture_bias ? posture_bias[lane] : T(0));
+  if (lane < 2) cact[E * 2 + lane] = 1;
+  // CoP task reference: between the soles, on the floor
+  if (cop_ref && lane < 3) cop_ref[E * 3 + lane] = lane < 2 ? T(0.5) * (L.oMf[0][9 + lane] + L.oMf[1][9 + lane]) : T(0);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_walk(int n, WalkArgs<T> wa) {
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int e = gid >> 4, r = gid & 15;
+  if (e >= n) return;
+  walk_update_env<T>(wa, e, r);
 }
 
 // ---------------------------------------------------------------------------- episode plan on the device
@@ -565,6 +598,7 @@ void tree_tables(const int *parent, int n, int *depth, int *nchild, int (*child)
 
 struct tsidb_ctx {
   int device = 0, dtype = 0, num_envs = 0;
+  int sim_waves = 1; // wavefronts per env in k_sim (tsidb_set_option)
   Blob blob;
   std::vector<double> params;
   void *d_model = nullptr, *d_hull = nullptr, *d_box = nullptr;
@@ -831,13 +865,17 @@ static void need_refs(tsidb_ctx *h) {
 template <typename T>
 static void launch_tick(tsidb_ctx *h, void *q, void *v, void *tau, void *dv, void *f, int32_t *status, void *obs, int obs_ld,
                         void *frames, int32_t *info, hipStream_t s, const void *qpos_sim = nullptr,
-                        const void *qvel_sim = nullptr) {
+                        const void *qvel_sim = nullptr, const WalkArgs<T> *walk = nullptr, void *q_snap = nullptr, void *v_snap = nullptr) {
   if (obs && obs_ld < NOBS) throw std::string("obs row stride must be at least TSIDB_NOBS");
+  WalkArgs<T> wa;
+  memset(&wa, 0, sizeof wa);
+  if (walk) wa = *walk;
 #define TSIDB_LAUNCH_TICK(COP)                                                                                             \
   hipLaunchKernelGGL((k_tick<T, COP>), dim3(h->num_envs), dim3(WAVE), 0, s, (const DevModel<T> *)h->d_model, h->num_envs,   \
                      (T *)q, (T *)v, (const T *)h->com_ref, (const T *)h->posture_ref, (const T *)h->foot_ref,             \
                      (const T *)h->contact_ref, h->contact_active, (const T *)h->cop_frames, (T *)tau, (T *)dv, (T *)f,    \
-                     status, (T *)obs, obs_ld, (T *)frames, info, (const T *)qpos_sim, (const T *)qvel_sim, (const T *)h->cop_ref)
+                     status, (T *)obs, obs_ld, (T *)frames, info, (const T *)qpos_sim, (const T *)qvel_sim, (const T *)h->cop_ref, wa, \
+                     (T *)q_snap, (T *)v_snap)
   if (h->params[P_W_COP] != 0.0) TSIDB_LAUNCH_TICK(true);
   else TSIDB_LAUNCH_TICK(false);
 #undef TSIDB_LAUNCH_TICK
@@ -847,10 +885,35 @@ template <typename T>
 static void launch_sim(tsidb_ctx *h, const void *q_tsid, const void *v_tsid, void *qpos, void *qvel, void *qacc_ws, void *qacc,
                        int32_t *ncon, int32_t *con, int32_t *info, hipStream_t s, const void *motor_tau = nullptr) {
   if constexpr (!TOPO_HAS_SIM) throw std::string("this library was built without the sim stage");
-  else
-  hipLaunchKernelGGL(k_sim<T>, dim3(h->num_envs), dim3(WAVE), 0, s, (const DevModel<T> *)h->d_model, h->num_envs,
-                     (const T *)q_tsid, (const T *)v_tsid, (T *)qpos, (T *)qvel, (T *)qacc_ws, (const T *)h->env_params, (const T *)h->terrain, (const T *)motor_tau, (T *)qacc, ncon, con, info);
+  else {
+    // while every wavefront of the step is resident at once (1024 SIMDs x 2; the tick kernel of the next step runs beside
+    // the sim: 3 N <= 2048) a step costs one wavefront's latency: two wavefronts per env there (collision beside the
+    // unconstrained dynamics), bit-identical results.  Measured: 512 envs sim 0.083 -> 0.077 ms; at 1024 and 2048 envs the
+    // extra wavefronts queue behind the others and nothing is gained
+#define TSIDB_LAUNCH_SIM(NW)                                                                                                      \
+    hipLaunchKernelGGL((k_sim<T, NW>), dim3(h->num_envs), dim3(WAVE * NW), 0, s, (const DevModel<T> *)h->d_model, h->num_envs,        \
+                       (const T *)q_tsid, (const T *)v_tsid, (T *)qpos, (T *)qvel, (T *)qacc_ws, (const T *)h->env_params,         \
+                       (const T *)h->terrain, (const T *)motor_tau, (T *)qacc, ncon, con, info)
+    if (h->sim_waves == 2) TSIDB_LAUNCH_SIM(2);
+    else TSIDB_LAUNCH_SIM(1);
+#undef TSIDB_LAUNCH_SIM
+  }
   HIP_OK(hipGetLastError());
+}
+
+// tsidb_walk_args (include/tsidb.h) -> the kernel's argument block, with the registered reference buffers
+template <typename T>
+static WalkArgs<T> walk_args(tsidb_ctx *h, const tsidb_walk_args *a) {
+  if (!a->coef || !a->side || !a->nsteps || !a->rest || !a->com || !a->frames || a->K <= 0) throw std::string("walking reference update: null table or K <= 0");
+  if (!(a->step_duration > 0) || !(a->omega > 0) || a->t_start < 0) throw std::string("walking reference update: bad timing");
+  if (a->td_latch && (!a->ncon || !a->con_pairs)) throw std::string("walking reference update: touch-down feedback needs ncon and con_pairs");
+  WalkArgs<T> w;
+  w.coef = (const T *)a->coef; w.side = a->side; w.nsteps = a->nsteps; w.rest = (const T *)a->rest; w.com = (const T *)a->com; w.K = a->K;
+  w.t_now = (T)a->t; w.t_off = (const T *)a->t_offset; w.Tstep = (T)a->step_duration; w.t_start = (T)a->t_start; w.omega = (T)a->omega;
+  w.z0 = (T)a->com_z0; w.dz = (T)a->com_drop; w.frames = (const T *)a->frames; w.foot_ref = (T *)h->foot_ref; w.contact_ref = (T *)h->contact_ref;
+  w.cact = (uint8_t *)h->contact_active; w.com_ref = (T *)h->com_ref; w.ncon = a->ncon; w.con = a->con_pairs; w.latch = a->td_latch;
+  w.fgeoms0 = h->foot_geoms[0]; w.fgeoms1 = h->foot_geoms[1]; w.td_frac = (T)a->td_fraction; w.t_dev = a->t_device;
+  return w;
 }
 
 template <typename T>
@@ -879,6 +942,7 @@ int tsidb_create(const void *model_blob, size_t nbytes, const double *params, in
     if (num_envs <= 0) throw std::string("num_envs must be positive");
     if (dtype != TSIDB_F64 && dtype != TSIDB_F32) throw std::string("dtype must be TSIDB_F64 or TSIDB_F32");
     h->device = device; h->dtype = dtype; h->num_envs = num_envs;
+    h->sim_waves = num_envs <= 640 ? 2 : 1; // every wavefront of both kernels resident at once: 3 N <= 2048 slots
     h->blob.raw.assign((const uint8_t *)model_blob, (const uint8_t *)model_blob + nbytes);
     h->blob.validate();
     { // the blob must be for the robot this library was built for
@@ -949,6 +1013,13 @@ int tsidb_set_refs(tsidb_handle h, const void *com_ref, const void *posture_ref,
   h->com_ref = com_ref; h->posture_ref = posture_ref; h->foot_ref = foot_ref;
   h->contact_ref = contact_ref; h->contact_active = contact_active; h->cop_frames = cop_frames;
   return 0;
+}
+
+int tsidb_set_option(tsidb_handle h, int option, int value) {
+  if (!h) return -1;
+  if (option == TSIDB_OPT_SIM_WAVES && (value == 1 || value == 2)) { h->sim_waves = value; return 0; }
+  h->err = "tsidb_set_option: unknown option or value";
+  return 1;
 }
 
 int tsidb_set_cop_ref(tsidb_handle h, const void *cop_ref) {
@@ -1063,24 +1134,32 @@ int tsidb_walk_update(tsidb_handle h, const void *coef, const int32_t *side, con
                       int32_t *td_latch, double td_fraction, const void *t_device, void *stream) {
   GUARD_BEGIN
   need_refs(h);
-  if (!coef || !side || !nsteps || !rest || !com || !frames || K <= 0) throw std::string("tsidb_walk_update: null table or K <= 0");
-  if (!(step_duration > 0) || !(omega > 0) || t_start < 0) throw std::string("tsidb_walk_update: bad timing");
-  if (td_latch && (!ncon || !con_pairs)) throw std::string("tsidb_walk_update: touch-down feedback needs ncon and con_pairs");
+  const tsidb_walk_args a = {coef, side, nsteps, rest, com, K, t, step_duration, t_start, omega, com_z0, com_drop, frames, t_offset,
+                             ncon, con_pairs, td_latch, td_fraction, (const double *)t_device};
   hipStream_t s = (hipStream_t)stream;
   const int grid = (h->num_envs * 16 + 255) / 256;
-  if (h->dtype == TSIDB_F64)
-    hipLaunchKernelGGL(k_walk<double>, dim3(grid), dim3(256), 0, s, h->num_envs, (const double *)coef, side, nsteps,
-                       (const double *)rest, (const double *)com, K, t, (const double *)t_offset, step_duration, t_start, omega, com_z0, com_drop,
-                       (const double *)frames, (double *)h->foot_ref, (double *)h->contact_ref, (uint8_t *)h->contact_active,
-                       (double *)h->com_ref, ncon, con_pairs, td_latch, h->foot_geoms[0], h->foot_geoms[1], td_fraction,
-                       (const double *)t_device);
-  else
-    hipLaunchKernelGGL(k_walk<float>, dim3(grid), dim3(256), 0, s, h->num_envs, (const float *)coef, side, nsteps,
-                       (const float *)rest, (const float *)com, K, (float)t, (const float *)t_offset, (float)step_duration, (float)t_start, (float)omega,
-                       (float)com_z0, (float)com_drop, (const float *)frames, (float *)h->foot_ref, (float *)h->contact_ref,
-                       (uint8_t *)h->contact_active, (float *)h->com_ref, ncon, con_pairs, td_latch, h->foot_geoms[0], h->foot_geoms[1],
-                       (float)td_fraction, (const double *)t_device);
+  if (h->dtype == TSIDB_F64) hipLaunchKernelGGL(k_walk<double>, dim3(grid), dim3(256), 0, s, h->num_envs, walk_args<double>(h, &a));
+  else hipLaunchKernelGGL(k_walk<float>, dim3(grid), dim3(256), 0, s, h->num_envs, walk_args<float>(h, &a));
   HIP_OK(hipGetLastError());
+  GUARD_END
+}
+
+int tsidb_tick_walk(tsidb_handle h, const tsidb_walk_args *walk, void *q, void *v, void *tau, void *dv, void *f, int32_t *status,
+                    void *obs, int obs_ld, void *frames, int32_t *info, void *q_snapshot, void *v_snapshot, void *stream) {
+  GUARD_BEGIN
+  need_refs(h);
+  if (!q || !v || !tau || !dv || !f || !status) throw std::string("tsidb_tick_walk: null buffer");
+  if (h->dtype == TSIDB_F64) {
+    WalkArgs<double> wa;
+    if (walk) wa = walk_args<double>(h, walk);
+    launch_tick<double>(h, q, v, tau, dv, f, status, obs, obs_ld, frames, info, (hipStream_t)stream, nullptr, nullptr, walk ? &wa : nullptr,
+                        q_snapshot, v_snapshot);
+  } else {
+    WalkArgs<float> wa;
+    if (walk) wa = walk_args<float>(h, walk);
+    launch_tick<float>(h, q, v, tau, dv, f, status, obs, obs_ld, frames, info, (hipStream_t)stream, nullptr, nullptr, walk ? &wa : nullptr,
+                       q_snapshot, v_snapshot);
+  }
   GUARD_END
 }
 

@@ -34,25 +34,29 @@ template <typename T>
 struct SimLds {
   Floor<T> fl; // per-env floor frame: read where needed instead of ten live registers per lane
   T S[NV][6];
-  union { // tree-pass scratch is dead once bias forces and M exist; collision and the Newton loop reuse the space
+  union { // tree-pass scratch is dead once bias forces and M exist; the Newton loop reuses the space
     struct { T V[NB][6], A[NB][6], f[NB][6], Yc[NB][10]; };
     struct {
       T K[NB][21];      // per-body contact inertia (packed sym 6x6), composite over subtrees (Newton loop)
-      T hn[MAXHH][3];   // robot<->robot contacts: normal (geom1 -> geom2); written by the narrow phase
-      int hb1[MAXHH];   //                        body of geom1
-    };
-    struct {            // collision-time scratch over K.  fcand is read while the narrow phase writes hn / hb1 and
-                        // must stay inside K (asserted below); the rest is dead by then and may reach past it
-      int fcand[64];    // candidate pairs that passed the sphere and the box test: the narrow phase's work list
-      int pcand[128];   // candidate pairs that passed the bounding-sphere test (a batch list)
-      T terr[20];       // stepped-terrain table of this env
-      T scen[NG][4];    // bounding spheres of the geoms in the world (relative to O): centre, radius
+      T hn[MAXHH][3];   // robot<->robot contacts: normal (geom1 -> geom2); copied here from the staging below once the
+      int hb1[MAXHH];   //                        collision phase is over; body of geom1
     };
   };
   T M[NV * LDM];
   union { // body frames are needed until the contacts exist; per-contact inertias are folded into K
           // before the Hessian is assembled
-    struct { T R[NB][9], p[NB][3]; };
+    struct {
+      T R[NB][9], p[NB][3];
+      // collision-time scratch BEHIND the body frames (dead before the Newton loop writes Wc / H).  It used to overlay the
+      // tree-pass scratch; here it also survives the two-wavefront variant, where the collision phase runs beside the
+      // bias / mass-matrix phase that still reads f and Yc.
+      int fcand[64];    // candidate pairs that passed the sphere and the box test: the narrow phase's work list
+      int pcand[128];   // candidate pairs that passed the bounding-sphere test (a batch list)
+      T terr[20];       // stepped-terrain table of this env
+      T scen[NG][4];    // bounding spheres of the geoms in the world (relative to O): centre, radius
+      T hn_s[MAXHH][3]; // narrow-phase output (staging of hn / hb1)
+      int hb1_s[MAXHH];
+    };
     T H[NV * LDM];
     T Wc[MAXCON][21];
   };
@@ -62,8 +66,21 @@ struct SimLds {
   T ctq[CONDIM > 3 ? MAXCON : 1][3]; // contact torque vector about the contact point (torsional friction rows)
   unsigned anc[NB]; // ancestor bitmask per body (copied from the model: LDS latency, not global)
   T cr[MAXCON][3], cdist[MAXCON], cfv[MAXCON][3]; // contact point (rel O), distance, force vector
+  int xch[4]; // two-wavefront variant: ncon, nfl, cross-branch flag, flag bits handed from the collision wavefront to the other
 };
-static_assert(64 * sizeof(int) <= sizeof(float) * NB * 21, "the narrow phase's work list must not reach the contact normals");
+static_assert(sizeof(SimLds<double>) <= 20480, "k_sim must fit 8 workgroups per CU");
+
+// LDS hand-over between the lanes of ONE wavefront.  With one wavefront per workgroup (NW = 1) that is what __syncthreads()
+// is; in the two-wavefront variant the phases that run on different wavefronts at the same time must not meet at a
+// workgroup barrier, and need none: a wavefront's LDS instructions execute in order, only the compiler has to be told.
+template <int NW> __device__ __forceinline__ void wsync() {
+  if constexpr (NW == 1) __syncthreads();
+  else {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+}
 
 __device__ __forceinline__ int sym_idx(int i, int j) { // packed upper index of a symmetric 6x6
   const int a = i < j ? i : j, b = i < j ? j : i;
@@ -730,7 +747,7 @@ template <typename T> struct NewtonDir { T search; int status; };
 template <typename T>
 __device__ __noinline__ NewtonDir<T> newton_direction(const DevModel<T> &m, SimLds<T> &L, int nfl, int mode, unsigned chg, unsigned actbits,
                                                       T mu, T cD, T fD, T grad) {
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & (WAVE - 1);
   NewtonDir<T> out;
   out.search = 0;
   out.status = 0;
@@ -833,8 +850,13 @@ __device__ __forceinline__ void rows_eval(const RowState<T> &rs, T alpha, T &c, 
   }
 }
 
-template <typename T>
-__device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L, int lane, const T *q_tsid, const T *v_tsid, T *qpos_g, T *qvel_g,
+// NW = wavefronts per env.  1: the batch fills the GPU, one wavefront per env is the throughput-optimal shape.  2 (small
+// batches, where a step costs one wavefront's LATENCY and half the SIMDs idle): after the kinematics - which both wavefronts
+// run, redundantly and in lockstep - wavefront 1 does the collision phase while wavefront 0 builds bias forces and the mass
+// matrix, factors it and solves for the unconstrained acceleration; they join before the constraint rows, and wavefront 0
+// finishes the step alone.  Same operations on the same data: results are bit-identical to NW = 1.
+template <typename T, int NW>
+__device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L, int lane, int wv, const T *q_tsid, const T *v_tsid, T *qpos_g, T *qvel_g,
                              T *qacc_ws_g, const T *envp, const T *terr_g, const T *motor_tau, T *qacc_out, int *ncon_out, int *con_out,
                              int *info) {
   // per-env randomisation (BASELINE config 5), NULL = nominal: mass scale, contact friction, floor plane
@@ -1000,8 +1022,10 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
     }
   }
   __syncthreads();
+  const bool w_dyn = NW == 1 || wv == 0, w_col = NW == 1 || wv == NW - 1; // which phases this wavefront runs
   // ---- per dof: bias, mass-matrix column (+ armature), actuation
   T qfs = 0;
+  if (w_dyn) {
   if (lane < NV) {
     const int k = lane, bk = k < 6 ? 0 : k - 5;
     T Sk[6], Fk[6], hk = 0;
@@ -1022,7 +1046,7 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
     }
     qfs = -hk;
   }
-  __syncthreads();
+  wsync<NW>();
   if (lane < NV) L.M[lane * LDM + lane] += m.mj_armature[lane];
   if (lane < NA) {
     const int d = m.mj_act_dof[lane];
@@ -1034,11 +1058,12 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
     servo = servo < m.act_range[lane][2] ? m.act_range[lane][2] : (servo > m.act_range[lane][3] ? m.act_range[lane][3] : servo);
     L.xv[d] = motor_tau ? motor_tau[m.mj_ctrl_qidx[lane] - 7] : servo;
   } else if (lane >= 32 && lane < 38) L.xv[lane - 32] = 0;
-  __syncthreads();
+  wsync<NW>();
   if (lane < NV) qfs += L.xv[lane];
   if constexpr (EULERDAMP) { // passive joint damping (robot/v0/robot.xml:3)
     if (lane < NV) qfs -= m.mj_damping[lane] * L.qvel[lane];
   }
+  } // (w_dyn)
   // ---- floor collision, first half: bounding-sphere pretest for all geoms at once (lane = geom, placed by its body).
   //      Done BEFORE the factorisation below (nothing of it stays live across it); only the geoms that can reach the
   //      floor enter the support search later, in geom order
@@ -1073,23 +1098,29 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
   TSIDB_STAMP(17);
   // ---- qacc_smooth = M^-1 qfrc_smooth
   T arow[NV];
-#pragma unroll
-  for (int j = 0; j < NV; j++) arow[j] = lane < NV ? L.M[lane * LDM + j] : T(0);
-  bool spd;
-  T qas = chol26_solve<T, false>(arow, qfs, lane, spd);
-  int fail = spd ? 0 : 1;
+  T qas = 0;
+  int fail = 0;
   // park the two per-lane values that live across the collision phase in LDS (the contact-force scratch is free until
   // the Newton loop): left in registers they are what the compiler spills to scratch around the narrow phase
   T *park = &L.cfv[0][0];
-  if (lane < NV) { park[lane] = qas; park[NV + lane] = qfs; }
+  if (w_dyn) {
+#pragma unroll
+    for (int j = 0; j < NV; j++) arow[j] = lane < NV ? L.M[lane * LDM + j] : T(0);
+    bool spd;
+    qas = chol26_solve<T, false>(arow, qfs, lane, spd);
+    fail = spd ? 0 : 1;
+    if (lane < NV) { park[lane] = qas; park[NV + lane] = qfs; }
+  }
 
   TSIDB_STAMP(18);
+  int ncon = 0, nfl = 0, cfail = 0; // contacts, floor contacts among them, flag bits of the collision phase
+  bool hh_cross = false; // some robot<->robot contact couples two branches of the tree (dense Newton Hessian)
+  if (w_col) {
   // ---- collision: floor (plane n.x = d, nominal z = 0, optionally with terrain steps) against each body's hull
-  if (has_terr) { // the tree-pass scratch is dead: stage this env's terrain table over it
+  if (has_terr) { // stage this env's terrain table
     if (lane < 20) L.terr[lane] = terr_g[lane];
-    __syncthreads();
+    wsync<NW>();
   }
-  int ncon = 0;
   const bool pm_rule = m.params[P_PLANE_MESH] != 0; // upstream's plane <-> mesh rule instead of "every neighbour in the margin"
   for (unsigned long long bm = cand_geoms; bm; bm &= bm - 1) {
     const int g = __ffsll((long long)bm) - 1, b = m.geom_body[g];
@@ -1108,7 +1139,7 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
     // the support vertex, then its hull-graph neighbours within the margin
     const int e0 = m.hull_eadr[best];
     int nnb = m.hull_eadr[best + 1] - e0;
-    if (nnb > WAVE - 1) { nnb = WAVE - 1; fail |= 16; }
+    if (nnb > WAVE - 1) { nnb = WAVE - 1; cfail |= 16; }
     bool keep = false;
     T w[3] = {0, 0, 0}, wd = 0;
     int vid = best;
@@ -1131,7 +1162,7 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
       keep = lane == 0 || (far && __popcll(fm & ((1ull << lane) - 1ull)) < 3);
     }
     const unsigned long long mask = __ballot(keep);
-    if (ncon + __popcll(mask) > MAXCON) fail |= 8; // a contact is dropped at the cap
+    if (ncon + __popcll(mask) > MAXCON) cfail |= 8; // a contact is dropped at the cap
     const int slot = ncon + __popcll(mask & ((1ull << lane) - 1ull));
     if (keep && slot < MAXCON) {
       const T dist = wd;
@@ -1145,10 +1176,9 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
     ncon += __popcll(mask);
     ncon = ncon > MAXCON ? MAXCON : ncon;
   }
-  const int nfl = ncon; // contacts [0, nfl) are floor contacts (shared frame), [nfl, ncon) robot<->robot ones
+  nfl = ncon; // contacts [0, nfl) are floor contacts (shared frame), [nfl, ncon) robot<->robot ones
   // ---- collision: robot<->robot convex-hull pairs (robot.xml:13-15 after the excludes of :18-52 and the
   //      parent-child filter): mid phase one lane per pair, narrow phase (MPR) one pair at a time on the wave
-  bool hh_cross = false; // some robot<->robot contact couples two branches of the tree (dense Newton Hessian)
 #ifndef TSIDB_NO_HH
   if (m.params[P_SELF_COLLISION] != 0) {
     // bounding spheres of all bodies in the world (lane = body)
@@ -1159,7 +1189,7 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
       L.scen[lane][0] = c[0] + L.p[gb][0]; L.scen[lane][1] = c[1] + L.p[gb][1]; L.scen[lane][2] = c[2] + L.p[gb][2];
       L.scen[lane][3] = m.rbound[lane][3];
     }
-    __syncthreads();
+    wsync<NW>();
     // broad phase, one lane per pair: sphere test, survivors compacted into a list; the box test then runs on the list
     // 64 entries at a time (once, at the end, for the v1 robot's ~30 survivors; the v0 robot has 1044 pairs)
     int nsph = 0, ncand = 0;
@@ -1179,19 +1209,19 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
       if (may) L.pcand[nsph + __popcll(mk & ((1ull << lane) - 1ull))] = k; // nsph <= 64 here: the list holds 128
       nsph += __popcll(mk);
       if (nsph > WAVE) {
-        __syncthreads();
+        wsync<NW>();
         box_pass(WAVE);
         const int rest = lane < nsph - WAVE ? L.pcand[WAVE + lane] : 0;
-        __syncthreads();
+        wsync<NW>();
         if (lane < nsph - WAVE) L.pcand[lane] = rest;
         nsph -= WAVE;
-        __syncthreads();
+        wsync<NW>();
       }
     }
-    __syncthreads();
+    wsync<NW>();
     box_pass(nsph);
     if (ncand > WAVE) { ncand = WAVE; over64 = true; }
-    __syncthreads();
+    wsync<NW>();
     for (int ci = 0; ci < ncand; ci++) {
       const int k = L.fcand[ci];
       const int ga = m.pair_a[k], gb = m.pair_b[k], a = m.geom_body[ga], b = m.geom_body[gb]; // geoms, their bodies
@@ -1203,17 +1233,34 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
         L.cgeom[ncon] = gb;
         L.cvert[ncon] = 0x8000 | ga;
         L.cdist[ncon] = margin - depth;
-        L.hb1[ncon - nfl] = a;
+        L.hb1_s[ncon - nfl] = a;
 #pragma unroll
-        for (int i = 0; i < 3; i++) { L.cr[ncon][i] = pos[i]; L.hn[ncon - nfl][i] = dir[i]; }
+        for (int i = 0; i < 3; i++) { L.cr[ncon][i] = pos[i]; L.hn_s[ncon - nfl][i] = dir[i]; }
       }
       if (!((bodyanc_of(m, b) >> a) & 1u) && !((bodyanc_of(m, a) >> b) & 1u)) hh_cross = true;
       ncon++;
     }
-    if (over) fail |= 8;
-    if (over64) fail |= 32;
+    if (over) cfail |= 8;
+    if (over64) cfail |= 32;
   }
 #endif
+  } // (w_col)
+  if constexpr (NW > 1) { // join: the collision wavefront hands over its counts and is done
+    if (wv == NW - 1 && lane == 0) { L.xch[0] = ncon; L.xch[1] = nfl; L.xch[2] = hh_cross ? 1 : 0; L.xch[3] = cfail; }
+    __syncthreads();
+    if (wv != 0) return;
+    ncon = L.xch[0]; nfl = L.xch[1]; hh_cross = L.xch[2] != 0; cfail = L.xch[3];
+  }
+  fail |= cfail;
+  { // the robot<->robot contacts' normals and geom1 bodies move from the collision scratch to where the Newton loop keeps them
+    T hv = 0;
+    int hb = 0;
+    if (lane < 3 * MAXHH) hv = (&L.hn_s[0][0])[lane];
+    if (lane < MAXHH) hb = L.hb1_s[lane];
+    __syncthreads();
+    if (lane < 3 * MAXHH) (&L.hn[0][0])[lane] = hv;
+    if (lane < MAXHH) L.hb1[lane] = hb;
+  }
   __syncthreads();
   qas = lane < NV ? park[lane] : T(0);
   qfs = lane < NV ? park[NV + lane] : T(0);
@@ -1324,9 +1371,9 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
     // (float32: the solver tolerance 1e-8 is below the rounding noise of the cost, so a converged env used to pass the
     //  improvement test by noise, build and factor a second Hessian and then find no step: the tolerance is floored at
     //  64 ulp there - no effect in float64)
-    const T tol = m.opt[2] > 64 * Eps<T>::v ? m.opt[2] : 64 * Eps<T>::v, ls_tol = m.opt[5];
-    const int maxiter = (int)m.opt[3], ls_iter = (int)m.opt[4];
-    const T scale = T(1) / (m.meaninertia * NV);
+    // (read where they are used, every iteration: kept from here they are loop-invariant values in registers the loop
+    //  does not have - the compiler parked them in scratch memory and reloaded them inside the loop)
+    auto solver_tol = [&]() { asm volatile("" ::: "memory"); const T t0 = m.opt[2]; return t0 > 64 * Eps<T>::v ? t0 : 64 * Eps<T>::v; };
     T cost = 0;
     int iter = 0;
     // Newton Hessian H = M + J^T D J over the rows in their quadratic zone: built and factored in full on the first
@@ -1408,12 +1455,13 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
       }
       if (iter > 0) {
         const T gn = wave_sum(grad * grad);
+        const T tol = solver_tol(), scale = T(1) / (m.meaninertia * NV);
         const T improvement = scale * (cost - newcost), gradient = scale * sqrt(gn);
         cost = newcost;
         if (improvement < tol || gradient < tol) break;
       }
       cost = newcost;
-      if (iter >= maxiter) break;
+      if (iter >= (int)m.opt[3]) break;
       TSIDB_LAP(24);
       unsigned actbits = fact ? 1u : 0u;
       if (rs.has_c) {
@@ -1473,40 +1521,58 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
             }
         }
       }
-      for (int i = lane; i < NB * 21; i += WAVE) (&L.K[0][0])[i] = 0;
       __syncthreads();
-      // composite contact inertia: contacts arrive grouped by body; lane e sums entry e of the group
-      // and pushes it to every ancestor of that body (subtree sums without a depth loop)
+      // composite contact inertia K[a] = sum of the contact inertias of every body in a's subtree.  Contacts arrive grouped
+      // by body.  Stage 1: lane e sums entry e over each group, in place (the group's first contact keeps the sum).  Stage 2:
+      // the 21 NB entries of K are dealt to the lanes, each adds up the groups whose body has `a` among its ancestors -
+      // plain loads and one store per entry (the first version pushed every group sum to every ancestor with dependent
+      // LDS read-modify-writes, after zeroing K: 3-4 k cycles of latency per build; same sums in the same order)
       unsigned touched = 0;
+      unsigned long long gfirst; // bit c: floor contact c is the first of its body's group
       {
-        T accK = 0;
-        for (int c = 0; c < nfl; c++) { // floor contacts; the robot<->robot ones are added below as rank-3 terms
-          const int b = L.cbody[c];
-          if (lane < 21) accK += L.Wc[c][lane];
-          if (c + 1 == nfl || L.cbody[c + 1] != b) {
-            const unsigned am = L.anc[b];
-            for (unsigned mk = am; mk; mk &= mk - 1) {
-              const int a = __ffs(mk) - 1;
-              if (lane < 21) L.K[a][lane] += accK;
-            }
-            touched |= am;
-            accK = 0;
+        const bool isfirst = lane < nfl && (lane == 0 || L.cbody[lane] != L.cbody[lane > 0 ? lane - 1 : 0]);
+        gfirst = __ballot(isfirst);
+        for (unsigned long long gm = gfirst; gm; gm &= gm - 1) {
+          const int cf = __ffsll((long long)gm) - 1;
+          const unsigned long long rest = gm & (gm - 1);
+          const int ce = rest ? __ffsll((long long)rest) - 1 : nfl;
+          touched |= L.anc[L.cbody[cf]];
+          if (lane < 21) {
+            T acc = 0;
+            for (int c = cf; c < ce; c++) acc += L.Wc[c][lane];
+            L.Wc[cf][lane] = acc;
           }
+        }
+      }
+      __syncthreads();
+      for (int id = lane; id < NB * 21; id += WAVE) {
+        const int a = id / 21, e = id - 21 * a;
+        T acc = 0;
+        for (unsigned long long gm = gfirst; gm; gm &= gm - 1) {
+          const int cf = __ffsll((long long)gm) - 1;
+          if ((L.anc[L.cbody[cf]] >> a) & 1u) acc += L.Wc[cf][e];
+        }
+        L.K[a][e] = acc;
+      }
+      // (K sits in the tree-pass scratch, Wc in the H region: H is written only after the barrier below)
+      __syncthreads();
+      T Gk[6] = {0, 0, 0, 0, 0, 0};
+      const bool mine = lane < NV && ((touched >> (lane < 6 ? 0 : lane - 5)) & 1u);
+      if (mine) { // G = K[body of dof k] S_k, before Wc's space becomes H
+        const int k = lane, bk = k < 6 ? 0 : k - 5;
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+          T sacc = 0;
+#pragma unroll
+          for (int j = 0; j < 6; j++) sacc += L.K[bk][sym_idx(i, j)] * L.S[k][j];
+          Gk[i] = sacc;
         }
       }
       __syncthreads();
       for (int i = lane; i < NV * LDM; i += WAVE) L.H[i] = L.M[i];
       __syncthreads();
-      if (lane < NV && ((touched >> (lane < 6 ? 0 : lane - 5)) & 1u)) {
-        const int k = lane, bk = k < 6 ? 0 : k - 5;
-        T G[6];
-#pragma unroll
-        for (int i = 0; i < 6; i++) {
-          T s = 0;
-#pragma unroll
-          for (int j = 0; j < 6; j++) s += L.K[bk][sym_idx(i, j)] * L.S[k][j];
-          G[i] = s;
-        }
+      if (mine) { // H[i][k] = H[k][i] = M[i][k] + S_i . G_k for the dofs i <= k on k's root path: written once, by lane k alone
+        const int k = lane;
         for (unsigned mk = L.anc[lane < 6 ? 0 : lane - 5]; mk; mk &= mk - 1) { // (from LDS: the register copy would be spilled)
           const int a = __ffs(mk) - 1;
           const int i0 = a == 0 ? 0 : 5 + a, i1 = a == 0 ? 5 : 5 + a;
@@ -1514,12 +1580,14 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
             if (i > k) continue;
             T val = 0;
 #pragma unroll
-            for (int e = 0; e < 6; e++) val += L.S[i][e] * G[e];
-            L.H[i * LDM + k] += val;
-            if (i != k) L.H[k * LDM + i] += val;
+            for (int e = 0; e < 6; e++) val += L.S[i][e] * Gk[e];
+            const T hv = L.M[i * LDM + k] + val;
+            L.H[i * LDM + k] = hv;
+            L.H[k * LDM + i] = hv;
           }
         }
       }
+      __syncthreads();
       if (fact) L.H[lane * LDM + lane] += rs.fD;
       __syncthreads();
       // robot<->robot contacts (rare): H += J^T A J with J = the contact point's relative velocity per unit dof
@@ -1587,7 +1655,8 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
       wave_sum3(qg1, qg2, snorm);
       snorm = sqrt(snorm);
       if (snorm < MINVAL) break;
-      const T gtol = tol * ls_tol * snorm * m.meaninertia * NV;
+      const T gtol = solver_tol() * m.opt[5] * snorm * m.meaninertia * NV;
+      const int ls_iter = (int)m.opt[4];
       auto ls_eval = [&](T alpha, T &c, T &d1, T &d2) {
         T lc, lg, lh;
         rows_eval(rs, alpha, lc, lg, lh);

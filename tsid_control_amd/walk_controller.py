@@ -85,6 +85,9 @@ class WalkController:
         rc = L.tsidb_set_refs(self._h, _ptr(self.com_ref), _ptr(self.posture_ref), _ptr(self.foot_ref),
                               _ptr(self.contact_ref), _ptr(self.contact_active), _ptr(self.cop_frames))
         _lib.check(L, self._h, rc, "tsidb_set_refs")
+        sw = int(getattr(conf, "sim_waves", 0))   # 0 = the library's choice (2 wavefronts per env up to 640 envs, else 1)
+        if sw:
+            _lib.check(L, self._h, L.tsidb_set_option(self._h, 1, sw), "tsidb_set_option(sim_waves)")
         self.cop_ref = z(N, 3)   # reference of the CoP force task (legacy/biped.py:79-80; conf.w_cop)
         _lib.check(L, self._h, L.tsidb_set_cop_ref(self._h, _ptr(self.cop_ref)), "tsidb_set_cop_ref")
 
@@ -257,14 +260,14 @@ class WalkController:
         self.t += n_substeps * self.conf.dt
         return self.tau, self.q, self.v, self.status, self.obs
 
-    def step_pipelined(self, events=None):
+    def step_pipelined(self, events=None, walk=None):
         """One env step with the sim stage left running on a second HIP stream, so that it overlaps with
         what the caller enqueues next on the current stream - normally the reference update and the TSID
         tick of the NEXT step.  The reference couples the two stages one way (the sim never feeds back into
         TSID, main.py:119-129 vs :192-195), so sim(t) and tick(t+1) are independent; the TSID state is
         handed to the sim through a two-slot snapshot.  tau, q, v, status, obs are valid on the current
         stream as after step(); the sim state (qpos, qvel, qacc_warmstart, ncon, con_pairs, info[:, 2:4])
-        is valid after sync_sim() ONLY: with conf.pipeline_sim_batch > 1 (the default for up to 1024 envs is 4) the
+        is valid after sync_sim() ONLY (walk = (schedule, t) runs that tick's WalkSchedule.apply inside the tick's launch): with conf.pipeline_sim_batch > 1 (the default for up to 1024 envs is 4) the
         last few sim stages are not even launched until the batch is full, so a device / stream synchronize does
         not make the sim state current - sync_sim() launches them and makes the current stream wait.  Every entry
         point of this class that reads or rewrites sim-side data (step, sim_step, reset, set_params, set_env_params,
@@ -274,21 +277,24 @@ class WalkController:
             raise _lib.TsidbError("step_pipelined needs the open-loop sim stage (closed loop: the tick reads the sim state)")
         cur = torch.cuda.current_stream(self.device)
         if getattr(self, "_pipe", None) is None:
-            K = 2 * self.sim_batch
+            # ring of snapshot slots: the tick writes its slot itself, so it must wait for the sim that read the slot
+            # K steps ago BEFORE it starts - with only two slots that wait held tick(t) back until sim(t - 2) was done
+            # and cost 12 % at 4096 envs; four slots and the tick stream runs ahead as before
+            K = max(4, 2 * self.sim_batch)
             self._pipe = dict(stream=torch.cuda.Stream(device=self.device), par=0, done=[None] * K, pending=[],
                               q=[torch.empty_like(self.q) for _ in range(K)], v=[torch.empty_like(self.v) for _ in range(K)])
         P = self._pipe
         par = P["par"]
         P["par"] = (par + 1) % len(P["q"])
-        if events:
-            events[0].record(cur)
-        self.tick()
-        if events:
-            events[1].record(cur)
         if P["done"][par] is not None:
             cur.wait_event(P["done"][par])     # the sim that read this slot 2 * sim_batch steps ago
-        P["q"][par].copy_(self.q)
-        P["v"][par].copy_(self.v)
+        if events:
+            events[0].record(cur)
+        # the tick writes the TSID state it ends on into the slot as well (two copy kernels less on this stream); walk =
+        # (schedule, t): the walking reference update of this tick in the same launch
+        self.tick(walk=walk, _snap=(P["q"][par], P["v"][par]))
+        if events:
+            events[1].record(cur)
         P["pending"].append(par)
         # conf.pipeline_sim_batch > 1 enqueues the sim stages that many at a time (one cross-stream wait and one record
         # per batch instead of per step; the sim state then lags the tick by up to that many steps until sync_sim()).
@@ -341,9 +347,7 @@ class WalkController:
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             for _ in range(n_steps):
-                if sched is not None:
-                    sched.apply(self, 0.0, t_device=self.t_device)
-                self.step_pipelined()
+                self.step_pipelined(walk=(sched, 0.0, self.t_device) if sched is not None else None)
                 self.t_device += dt
             self.sync_sim()                 # join the sim stream: the graph ends with every kernel done
         self._pipe["done"] = [None] * len(self._pipe["q"])
@@ -391,12 +395,22 @@ class WalkController:
             self._flush_sims()
             torch.cuda.current_stream(self.device).wait_stream(P["stream"])
 
-    def tick(self):
-        """TSID stage only (main.py:119-129)."""
+    def tick(self, walk=None, _snap=None):
+        """TSID stage only (main.py:119-129).  walk = (schedule, t): that tick's walking reference update
+        (WalkSchedule.apply(self, t)) runs in the same launch, ahead of the tick (tsidb_tick_walk) - same results."""
+        if walk is None and _snap is None:
+            with torch.cuda.device(self.device):
+                rc = self._L.tsidb_tick(self._h, _ptr(self.q), _ptr(self.v), _ptr(self.tau), _ptr(self.dv), _ptr(self.f),
+                                        _ptr(self.status), _ptr(self.rows), self.NROW, _ptr(self.frames), _ptr(self.info), self._stream())
+            _lib.check(self._L, self._h, rc, "tsidb_tick")
+            return self.tau, self.q, self.v, self.status, self.obs
+        wa = walk[0].args(self, walk[1], *walk[2:]) if walk is not None else None
+        qs, vs = _snap if _snap is not None else (None, None)
         with torch.cuda.device(self.device):
-            rc = self._L.tsidb_tick(self._h, _ptr(self.q), _ptr(self.v), _ptr(self.tau), _ptr(self.dv), _ptr(self.f),
-                                    _ptr(self.status), _ptr(self.rows), self.NROW, _ptr(self.frames), _ptr(self.info), self._stream())
-        _lib.check(self._L, self._h, rc, "tsidb_tick")
+            rc = self._L.tsidb_tick_walk(self._h, C.byref(wa) if wa is not None else None, _ptr(self.q), _ptr(self.v), _ptr(self.tau),
+                                         _ptr(self.dv), _ptr(self.f), _ptr(self.status), _ptr(self.rows), self.NROW, _ptr(self.frames),
+                                         _ptr(self.info), _ptr(qs), _ptr(vs), self._stream())
+        _lib.check(self._L, self._h, rc, "tsidb_tick_walk")
         return self.tau, self.q, self.v, self.status, self.obs
 
     def sim_step(self, teleport=True, q_tsid=None, v_tsid=None, _from_pipe=False):

@@ -358,6 +358,23 @@ class WalkSchedule:
         out[:, 2], out[:, 5], out[:, 8] = self.z0 - self.dz * sz, -self.dz * dsz, -self.dz * ddsz
         return out
 
+    def args(self, wc, t: float, t_device=None):
+        """This tick's reference update as the argument block of tsidb_tick_walk (WalkController.tick(walk=...) /
+        step_pipelined(walk=...)): the update then runs in the tick kernel's prologue instead of a launch of its own."""
+        from . import _lib
+        if not hasattr(self, "_side32"):   # (host-built schedule: int32 / contiguous copies for the kernel)
+            self._side32 = self.side.to(torch.int32).contiguous()
+            self._nsteps32 = self.nsteps.to(torch.int32).contiguous()
+            self._coef_c, self._rest_c, self._com_c = self.coef.contiguous(), self.rest.contiguous(), self.com.contiguous()
+        p = lambda x: x.data_ptr() if x is not None else None
+        fb = self.td_latch is not None
+        if fb:
+            wc.sync_sim()  # the kernel reads the last sim step's contact list: nothing of it may still be in flight
+        return _lib.WalkArgs(p(self._coef_c), p(self._side32), p(self._nsteps32), p(self._rest_c), p(self._com_c), self.K, float(t),
+                             float(self.conf.step_duration), float(self.t_start), float(self.omega), float(self.z0), float(self.dz),
+                             p(wc.frames), p(self.t_offset), p(wc.ncon) if fb else None, p(wc.con_pairs) if fb else None,
+                             p(self.td_latch) if fb else None, float(self.td_fraction), p(t_device))
+
     def apply(self, wc, t: float, t_device=None):
         """Device path of one tick's reference update: foot samples, contact switching and the CoM
         reference for every env in one kernel (tsidb_walk_update); equivalent to
