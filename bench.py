@@ -80,6 +80,9 @@ def parse():
                     help="N = 1, walk workload: capture this many pipelined steps in ONE HIP graph (WalkController.capture_steps) "
                          "and replay it - one launch instead of ~8 host calls per step; per-kernel event timing is not "
                          "available inside a graph")
+    ap.add_argument("--sim-batch", type=int, default=0,
+                    help="conf.pipeline_sim_batch: sim stages handed to the second stream this many at a time, in one launch "
+                         "(0 = the library's default: 4 up to 1024 envs, else 1)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary measurements (N = 1 only)")
     ap.add_argument("--secondary-steps", type=int, default=200)
     ap.add_argument("--event-every", type=int, default=int(os.environ.get("TSIDB_EVENT_EVERY", "8")),
@@ -189,6 +192,8 @@ def run_workload(a, dev, rank, world, n, with_gather=True):
         conf.reference_quirks = False
     if a.tau_max_scaling is not None:
         conf.tau_max_scaling = a.tau_max_scaling
+    conf.pipeline_sim_batch = int(getattr(a, "sim_batch", 0))
+    conf.sim_waves = int(os.environ.get("TSIDB_SIM_WAVES", "0"))   # (diagnostic override; 0 = the library's choice)
     wc = WalkController(conf, num_envs=n, device=dev)
     torch.manual_seed(1 + rank)
     if a.randomize:
@@ -377,7 +382,7 @@ def secondary_runs(a, dev):
     out = {}
     base = dict(dtype=a.dtype, randomize=False, dephase=0.0, tau_max_scaling=None, graph=0, steps=a.secondary_steps, warmup=20,
                 preroll=600, event_every=4, no_overlap=a.no_overlap, sync_gather=False, self_collision=a.self_collision,
-                robot="v1", closed_loop=False)
+                robot="v1", closed_loop=False, sim_batch=0)
     cases = [
         ("cfg2_stand_1024", dict(workload="stand", steps=max(a.secondary_steps, 400), warmup=200), 1024),
         ("cfg2_stand_4096", dict(workload="stand", steps=max(a.secondary_steps, 400), warmup=200), 4096),

@@ -74,7 +74,7 @@ int tsidb_set_refs(tsidb_handle h, const void *com_ref, const void *posture_ref,
 
 /* execution options that do not change results.  TSIDB_OPT_SIM_WAVES: wavefronts per env in the sim kernel - 1 (one wavefront
  * per env: the throughput-optimal shape once the batch fills the GPU) or 2 (collision phase on a second wavefront beside the
- * unconstrained dynamics: shorter step latency for small batches).  Default: 2 for up to 640 envs, else 1.  Bit-identical. */
+ * unconstrained dynamics: shorter step latency for small batches).  Default: 2 for up to 384 envs, else 1.  Bit-identical. */
 enum { TSIDB_OPT_SIM_WAVES = 1 };
 int tsidb_set_option(tsidb_handle h, int option, int value);
 
@@ -120,6 +120,15 @@ int tsidb_tick(tsidb_handle h, void *q, void *v, void *tau, void *dv, void *f, i
  * survived the mid phase (the rest is not collided). */
 int tsidb_sim(tsidb_handle h, const void *q_tsid, const void *v_tsid, void *qpos, void *qvel, void *qacc_ws,
               void *qacc, int32_t *ncon, int32_t *con_pairs, int32_t *info, void *stream);
+
+/* n_steps (1 .. TSIDB_MAX_SIM_BATCH) consecutive sim steps in ONE launch: step b teleports to / takes its joint targets from
+ * slot slots[b] (host array, 0 .. 15) of the snapshot rings q_ring [K,N,27], v_ring [K,N,26] (v_ring may be NULL) - what n_steps
+ * calls of tsidb_sim with q_tsid = q_ring[slots[b]] do, bit for bit, without the launch gaps between them (the pipelined
+ * open-loop step hands over the TSID states of several ticks at once; envs do not interact, so each steps on its own).
+ * ncon / con_pairs / info are the last step's. */
+enum { TSIDB_MAX_SIM_BATCH = 8 };
+int tsidb_sim_batch(tsidb_handle h, int n_steps, const void *q_ring, const void *v_ring, const int32_t *slots, void *qpos, void *qvel,
+                    void *qacc_ws, void *qacc, int32_t *ncon, int32_t *con_pairs, int32_t *info, void *stream);
 
 /* whole env step, n_substeps times: tsidb_tick then (if params[SIM_ENABLED]) tsidb_sim.
  * With params[CLOSED_LOOP] (not in the reference, whose coupling is one-way, main.py:126-129,

@@ -1411,3 +1411,28 @@ def test_two_wavefront_sim_is_bit_identical():
     for k in ("q", "v", "tau", "qpos", "qvel", "qacc_warmstart", "ncon", "con_pairs", "info", "rows"):
         assert torch.equal(getattr(a, k), getattr(b, k)), k
     assert int(a.ncon.max()) > 4 and int((a.con_pairs & 0x8000).bool().sum()) > 0     # floor and robot<->robot contacts were there
+
+
+def test_fused_walk_tick_and_device_episodes_in_the_pipelined_loop():
+    """the loop INTEGRATION.md shows - step_pipelined(walk=(sched, t)) (reference update + tick in one launch, the TSID state
+    snapshot written by the tick, sim on the second stream) with reset_done(sched) every step - against the plain sequence
+    apply(); step(); reset_done(): bit-identical, including an env that falls and restarts on a new path"""
+    n, dt = 32, 0.002
+    A, sa = _walker(n, seed=7)
+    B, sb = _walker(n, seed=7)
+    for i in range(260):
+        if i == 120:
+            A.q[5, 2] = 0.05
+            B.q[5, 2] = 0.05
+        sa.apply(A, i * dt)
+        A.step()
+        A.reset_done(sa, t=(i + 1) * dt)
+        B.step_pipelined(walk=(sb, i * dt))
+        B.reset_done(sb, t=(i + 1) * dt)
+    B.sync_sim()
+    torch.cuda.synchronize()
+    assert int(sa.episode[5]) == 1 and int(sb.episode[5]) == 1 and int(sa.episode.sum()) == 1
+    for k in ("q", "v", "tau", "dv", "f", "status", "rows", "qpos", "qvel", "qacc_warmstart", "ncon", "con_pairs", "contact_active",
+              "foot_ref", "com_ref", "contact_ref", "frames"):
+        assert torch.equal(getattr(A, k), getattr(B, k)), k
+    assert torch.equal(sa.coef, sb.coef) and torch.equal(sa.t_offset, sb.t_offset)

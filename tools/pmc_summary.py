@@ -35,7 +35,7 @@ for k, cs in sorted(acc.items()):
 if tj:
     mean = lambda k, c: sum(acc[k][c]) / len(acc[k][c]) if acc[k][c] else 0.0
     out = {}
-    for name, kernels in (("k_tick", [k for k in acc if k.startswith("k_tick<double")]), ("k_sim", ["k_sim<double>"])):
+    for name, kernels in (("k_tick", [k for k in acc if k.startswith("k_tick<double")]), ("k_sim", [k for k in acc if k.startswith("k_sim<double")])):
         fe = sum(mean(k, "FETCH_SIZE") for k in kernels)
         wr = sum(mean(k, "WRITE_SIZE") for k in kernels)
         out[name] = {"FETCH_SIZE_KiB": fe, "WRITE_SIZE_KiB": wr, "bytes_per_launch": 1024.0 * (fe + wr),
@@ -50,7 +50,7 @@ if tj:
     out["source"] = ("rocprofv3 --kernel-trace --pmc passes of tools/pmc_profile.sh: bench.py --steps 100 --warmup 5 "
                      "--no-overlap, last %s dispatches of each kernel" % (last or "all"))
     out["valu"] = {}
-    for name, kernels in (("k_tick", [k for k in acc if k.startswith("k_tick<double")]), ("k_sim", ["k_sim<double>"])):
+    for name, kernels in (("k_tick", [k for k in acc if k.startswith("k_tick<double")]), ("k_sim", [k for k in acc if k.startswith("k_sim<double")])):
         n_env = 4096.0
         g = lambda c: sum(mean(k, c) for k in kernels)
         out["valu"][name] = {"valu_inst_per_env": g("SQ_INSTS_VALU") / n_env, "salu_inst_per_env": g("SQ_INSTS_SALU") / n_env,

@@ -5,7 +5,7 @@ Compiles csrc/tsidb_api.hip to a throw-away object (the product .so is not touch
 import re, subprocess, sys, tempfile
 from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
-flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", *sys.argv[1:]]
+flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mllvm", "-disable-machine-licm", *sys.argv[1:]]
 with tempfile.TemporaryDirectory() as td:
     r = subprocess.run(["/opt/rocm/bin/hipcc", *flags, "-c", "-Rpass-analysis=kernel-resource-usage", "-o", f"{td}/x.o",
                         str(ROOT / "tsid_control_amd/csrc/tsidb_api.hip")], capture_output=True, text=True)
@@ -18,8 +18,8 @@ for line in r.stderr.splitlines():
     m = re.search(r"remark:\s+Function Name: (\S+)", line)
     if m:
         nm = m.group(1)
-        d = re.match(r"_Z\d+(k_[a-z]+)I([df])(Lb[01]|Li\d)?", nm)
-        cur = f"{d.group(1)}<{d.group(2)} {d.group(3) or ''}>" if d else nm
+        d = re.match(r"_Z\d+(k_[a-z]+)I([df])((?:L[bi]\dE?)*)", nm)
+        cur = f"{d.group(1)}<{d.group(2)} {d.group(3).replace('E', ' ').strip()}>" if d else nm
         rows[cur] = {}
         continue
     for k in keys:

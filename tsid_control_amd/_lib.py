@@ -11,7 +11,7 @@ LIB_PATH = Path(os.environ.get("TSIDB_LIB_PATH", _HERE / "libtsidb.so"))
 
 SYMBOLS = ["tsidb_dims", "tsidb_create", "tsidb_destroy", "tsidb_last_error", "tsidb_set_params", "tsidb_set_refs", "tsidb_reset",
            "tsidb_tick", "tsidb_sim", "tsidb_step", "tsidb_rbd_terms", "tsidb_lds_bytes", "tsidb_walk_update", "tsidb_set_env_params", "tsidb_set_cop_ref",
-           "tsidb_reset_done", "tsidb_set_posture_bias", "tsidb_walk_plan", "tsidb_set_option", "tsidb_tick_walk"]
+           "tsidb_reset_done", "tsidb_set_posture_bias", "tsidb_walk_plan", "tsidb_set_option", "tsidb_tick_walk", "tsidb_sim_batch"]
 
 _libs = {}
 
@@ -85,6 +85,7 @@ def load(path=None):
     L.tsidb_reset_done.argtypes = [vp, vp, C.c_int] + [vp] * 7
     L.tsidb_set_posture_bias.argtypes = [vp, vp]
     L.tsidb_set_option.argtypes = [vp, C.c_int, C.c_int]
+    L.tsidb_sim_batch.argtypes = [vp, C.c_int] + [vp] * 11
     L.tsidb_tick_walk.argtypes = [vp, vp] + [vp] * 7 + [C.c_int] + [vp] * 5
     L.tsidb_walk_plan.argtypes = [vp, vp, C.c_int, vp, C.c_int, vp, C.c_int, vp, vp, C.c_int, vp, vp, C.c_int, C.c_int] + [vp] * 9 + \
                                  [C.c_double, vp, vp]

@@ -210,9 +210,15 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2))) void 
   if (v_snap && lane < NV) v_snap[E * NV + lane] = L.vs[lane];
 }
 
-// NW = wavefronts per env: 1 when the batch fills the GPU, 2 for small batches (tsidb_sim.hpp: sim_step_env)
-template <typename T, int NW>
-__global__ __launch_bounds__(WAVE * NW) __attribute__((amdgpu_waves_per_eu(2))) void k_sim(const DevModel<T> *__restrict__ mp, int n, const T *q_tsid, const T *v_tsid, T *qpos, T *qvel,
+// NW = wavefronts per env: 1 when the batch fills the GPU, 2 for small batches (tsidb_sim.hpp: sim_step_env).
+// B consecutive sim steps per launch (tsidb_sim_batch; the pipelined open-loop step hands over a batch of TSID state snapshots):
+// envs do not interact, so each workgroup simply steps its env B times - no launch gaps between the steps, which at small
+// batches were 10 % of a step.  B = 1 is the plain tsidb_sim.
+// (the snapshots of a batch are slots of one [K, N, NQ] / [K, N, NV] ring: two base pointers and the slot numbers packed four
+//  bits each - sixteen separate pointers were 32 SGPRs live across the whole step body)
+template <typename T> struct SimRing { const T *q, *v; unsigned long long slots; };
+template <typename T, int NW, bool MULTI>
+__global__ __launch_bounds__(WAVE * NW) __attribute__((amdgpu_waves_per_eu(2))) void k_sim(const DevModel<T> *__restrict__ mp, int n, int B, SimRing<T> ring, T *qpos, T *qvel,
                                               T *qacc_ws, const T *env_params, const T *terrain, const T *motor_tau, T *qacc, int *ncon,
                                               int *con, int *info) {
   __shared__ SimLds<T> L;
@@ -220,30 +226,43 @@ __global__ __launch_bounds__(WAVE * NW) __attribute__((amdgpu_waves_per_eu(2))) 
   if ((int)blockIdx.x >= n) return;
   const int e = env_of_block(blockIdx.x, n);
   const size_t E = (size_t)e;
-  {
-    // non-finite sim state / targets, or a sim state that has diverged (sum of |qpos| + |qvel| beyond SIM_STATE_BOUND:
-    // the reference's own loop gets there, its teleported sim accumulates velocity until the contact forces explode -
-    // and products of such values overflow to inf / NaN inside the step): skip the step, failure bit 4 in info[3]
-    T chk = 0, big = 0;
-    if (lane < NQ) { big += fabs(qpos[E * NQ + lane]); chk += q_tsid ? fabs(q_tsid[E * NQ + lane]) : T(0); }
-    if (lane < NV) { big += fabs(qvel[E * NV + lane]); chk += fabs(qacc_ws[E * NV + lane]) + (v_tsid ? fabs(v_tsid[E * NV + lane]) : T(0)); }
-    if (lane < NA && motor_tau) chk += fabs(motor_tau[E * NA + lane]);
-    big = wave_sum(big);
-    if (__ballot(!(chk <= Eps<T>::inf)) || !(big <= T(SIM_STATE_BOUND))) {
-      if (wv == 0) {
+  for (int b = 0; b < (MULTI ? B : 1); b++) { // (MULTI = false: one step, no loop in the code at all)
+    // (the model pointer is laundered per step: otherwise every load of a model constant in the 1200-line step body is
+    //  loop-invariant, gets hoisted in front of the loop and stays live across the whole step - the kernel, at its register
+    //  limit already, then spilled a hundred values to scratch and ran 20 % slower)
+    const DevModel<T> *mq = mp;
+    if constexpr (MULTI) {
+      asm volatile("" : "+s"(mq), "+s"(qpos), "+s"(qvel), "+s"(qacc_ws), "+s"(env_params), "+s"(terrain), "+s"(motor_tau) : : "memory");
+      asm volatile("" : "+s"(qacc), "+s"(ncon), "+s"(con), "+s"(info) : : "memory");
+    }
+    const size_t slot = (size_t)((ring.slots >> (4 * b)) & 15ull);
+    const T *q_tsid = ring.q ? ring.q + slot * (size_t)n * NQ : nullptr, *v_tsid = ring.v ? ring.v + slot * (size_t)n * NV : nullptr;
+    bool skip;
+    {
+      // non-finite sim state / targets, or a sim state that has diverged (sum of |qpos| + |qvel| beyond SIM_STATE_BOUND:
+      // the reference's own loop gets there, its teleported sim accumulates velocity until the contact forces explode -
+      // and products of such values overflow to inf / NaN inside the step): skip the step, failure bit 4 in info[3]
+      T chk = 0, big = 0;
+      if (lane < NQ) { big += fabs(qpos[E * NQ + lane]); chk += q_tsid ? fabs(q_tsid[E * NQ + lane]) : T(0); }
+      if (lane < NV) { big += fabs(qvel[E * NV + lane]); chk += fabs(qacc_ws[E * NV + lane]) + (v_tsid ? fabs(v_tsid[E * NV + lane]) : T(0)); }
+      if (lane < NA && motor_tau) chk += fabs(motor_tau[E * NA + lane]);
+      big = wave_sum(big);
+      skip = __ballot(!(chk <= Eps<T>::inf)) || !(big <= T(SIM_STATE_BOUND));
+      if (skip && wv == 0) {
         if (lane == 0) {
           if (info) { info[E * 4 + 2] = 0; info[E * 4 + 3] = 4; }
           if (ncon) ncon[e] = 0;
         }
         if (con && lane < MAXCON) con[E * MAXCON + lane] = -1;
       }
-      return;
     }
+    if (!skip)
+      sim_step_env<T, NW>(*mq, L, lane, wv, q_tsid ? q_tsid + E * NQ : nullptr, v_tsid ? v_tsid + E * NV : nullptr, qpos + E * NQ, qvel + E * NV, qacc_ws + E * NV,
+                          env_params ? env_params + E * 8 : nullptr, terrain ? terrain + E * 20 : nullptr, motor_tau ? motor_tau + E * NA : nullptr,
+                          qacc ? qacc + E * NV : nullptr, ncon ? ncon + e : nullptr, con ? con + E * MAXCON : nullptr,
+                          info ? info + E * 4 : nullptr);
+    if constexpr (MULTI) __syncthreads(); // both wavefronts; the step's state is written before the next step reads it
   }
-  sim_step_env<T, NW>(*mp, L, lane, wv, q_tsid ? q_tsid + E * NQ : nullptr, v_tsid ? v_tsid + E * NV : nullptr, qpos + E * NQ, qvel + E * NV, qacc_ws + E * NV,
-                  env_params ? env_params + E * 8 : nullptr, terrain ? terrain + E * 20 : nullptr, motor_tau ? motor_tau + E * NA : nullptr,
-                  qacc ? qacc + E * NV : nullptr, ncon ? ncon + e : nullptr, con ? con + E * MAXCON : nullptr,
-                  info ? info + E * 4 : nullptr);
 }
 
 template <typename T>
@@ -882,23 +901,36 @@ static void launch_tick(tsidb_ctx *h, void *q, void *v, void *tau, void *dv, voi
   HIP_OK(hipGetLastError());
 }
 template <typename T>
-static void launch_sim(tsidb_ctx *h, const void *q_tsid, const void *v_tsid, void *qpos, void *qvel, void *qacc_ws, void *qacc,
+static void launch_sim(tsidb_ctx *h, int B, const void *q_ring, const void *v_ring, const int32_t *slots, void *qpos, void *qvel, void *qacc_ws, void *qacc,
                        int32_t *ncon, int32_t *con, int32_t *info, hipStream_t s, const void *motor_tau = nullptr) {
   if constexpr (!TOPO_HAS_SIM) throw std::string("this library was built without the sim stage");
   else {
+    if (B < 1 || B > TSIDB_MAX_SIM_BATCH) throw std::string("sim batch must be 1 .. TSIDB_MAX_SIM_BATCH steps");
+    SimRing<T> ring;
+    ring.q = (const T *)q_ring; ring.v = (const T *)v_ring; ring.slots = 0;
+    for (int b = 0; b < B; b++) {
+      const int sl = slots ? slots[b] : 0;
+      if (sl < 0 || sl > 15) throw std::string("sim batch: slot numbers must be 0 .. 15");
+      ring.slots |= (unsigned long long)sl << (4 * b);
+    }
     // while every wavefront of the step is resident at once (1024 SIMDs x 2; the tick kernel of the next step runs beside
     // the sim: 3 N <= 2048) a step costs one wavefront's latency: two wavefronts per env there (collision beside the
     // unconstrained dynamics), bit-identical results.  Measured: 512 envs sim 0.083 -> 0.077 ms; at 1024 and 2048 envs the
     // extra wavefronts queue behind the others and nothing is gained
-#define TSIDB_LAUNCH_SIM(NW)                                                                                                      \
-    hipLaunchKernelGGL((k_sim<T, NW>), dim3(h->num_envs), dim3(WAVE * NW), 0, s, (const DevModel<T> *)h->d_model, h->num_envs,        \
-                       (const T *)q_tsid, (const T *)v_tsid, (T *)qpos, (T *)qvel, (T *)qacc_ws, (const T *)h->env_params,         \
-                       (const T *)h->terrain, (const T *)motor_tau, (T *)qacc, ncon, con, info)
-    if (h->sim_waves == 2) TSIDB_LAUNCH_SIM(2);
-    else TSIDB_LAUNCH_SIM(1);
+#define TSIDB_LAUNCH_SIM(NW, MULTI)                                                                                                    \
+    hipLaunchKernelGGL((k_sim<T, NW, MULTI>), dim3(h->num_envs), dim3(WAVE * NW), 0, s, (const DevModel<T> *)h->d_model, h->num_envs, B, ring, \
+                       (T *)qpos, (T *)qvel, (T *)qacc_ws, (const T *)h->env_params, (const T *)h->terrain, (const T *)motor_tau,     \
+                       (T *)qacc, ncon, con, info)
+    if (B > 1) { if (h->sim_waves == 2) TSIDB_LAUNCH_SIM(2, true); else TSIDB_LAUNCH_SIM(1, true); }
+    else { if (h->sim_waves == 2) TSIDB_LAUNCH_SIM(2, false); else TSIDB_LAUNCH_SIM(1, false); }
 #undef TSIDB_LAUNCH_SIM
   }
   HIP_OK(hipGetLastError());
+}
+template <typename T>
+static void launch_sim(tsidb_ctx *h, const void *q_tsid, const void *v_tsid, void *qpos, void *qvel, void *qacc_ws, void *qacc,
+                       int32_t *ncon, int32_t *con, int32_t *info, hipStream_t s, const void *motor_tau = nullptr) {
+  launch_sim<T>(h, 1, q_tsid, v_tsid, nullptr, qpos, qvel, qacc_ws, qacc, ncon, con, info, s, motor_tau);
 }
 
 // tsidb_walk_args (include/tsidb.h) -> the kernel's argument block, with the registered reference buffers
@@ -942,7 +974,7 @@ int tsidb_create(const void *model_blob, size_t nbytes, const double *params, in
     if (num_envs <= 0) throw std::string("num_envs must be positive");
     if (dtype != TSIDB_F64 && dtype != TSIDB_F32) throw std::string("dtype must be TSIDB_F64 or TSIDB_F32");
     h->device = device; h->dtype = dtype; h->num_envs = num_envs;
-    h->sim_waves = num_envs <= 640 ? 2 : 1; // every wavefront of both kernels resident at once: 3 N <= 2048 slots
+    h->sim_waves = num_envs <= 384 ? 2 : 1; // (measured, DESIGN.md section 5 "small batches")
     h->blob.raw.assign((const uint8_t *)model_blob, (const uint8_t *)model_blob + nbytes);
     h->blob.validate();
     { // the blob must be for the robot this library was built for
@@ -1103,6 +1135,15 @@ int tsidb_sim(tsidb_handle h, const void *q_tsid, const void *v_tsid, void *qpos
   if (!qpos || !qvel || !qacc_ws) throw std::string("tsidb_sim: null state buffer");
   if (h->dtype == TSIDB_F64) launch_sim<double>(h, q_tsid, v_tsid, qpos, qvel, qacc_ws, qacc, ncon, con_pairs, info, (hipStream_t)stream);
   else launch_sim<float>(h, q_tsid, v_tsid, qpos, qvel, qacc_ws, qacc, ncon, con_pairs, info, (hipStream_t)stream);
+  GUARD_END
+}
+
+int tsidb_sim_batch(tsidb_handle h, int n_steps, const void *q_ring, const void *v_ring, const int32_t *slots, void *qpos, void *qvel,
+                    void *qacc_ws, void *qacc, int32_t *ncon, int32_t *con_pairs, int32_t *info, void *stream) {
+  GUARD_BEGIN
+  if (!qpos || !qvel || !qacc_ws || !q_ring || !slots) throw std::string("tsidb_sim_batch: null buffer");
+  if (h->dtype == TSIDB_F64) launch_sim<double>(h, n_steps, q_ring, v_ring, slots, qpos, qvel, qacc_ws, qacc, ncon, con_pairs, info, (hipStream_t)stream);
+  else launch_sim<float>(h, n_steps, q_ring, v_ring, slots, qpos, qvel, qacc_ws, qacc, ncon, con_pairs, info, (hipStream_t)stream);
   GUARD_END
 }
 

@@ -815,7 +815,7 @@ __device__ __noinline__ NewtonDir<T> newton_direction(const DevModel<T> &m, SimL
     for (int j = 0; j < NV; j++) L.H[lane * LDM + j] = arow[j];
     L.H[lane * LDM + NV] = rdv;
   }
-  __syncthreads(); // (one wavefront: orders the parked rows before the transposed read)
+  wsync<2>(); // (wavefront-local: orders the parked rows before the transposed read; only one wavefront is ever in here)
   out.search = chol26_subst<T>(arow, L.H, rdv, grad, lane);
   return out;
 }
@@ -1248,7 +1248,7 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
   if constexpr (NW > 1) { // join: the collision wavefront hands over its counts and is done
     if (wv == NW - 1 && lane == 0) { L.xch[0] = ncon; L.xch[1] = nfl; L.xch[2] = hh_cross ? 1 : 0; L.xch[3] = cfail; }
     __syncthreads();
-    if (wv != 0) return;
+    if (wv != 0) return; // (from here on only wavefront 0 works on this env's step: its LDS hand-overs are wavefront-local)
     ncon = L.xch[0]; nfl = L.xch[1]; hh_cross = L.xch[2] != 0; cfail = L.xch[3];
   }
   fail |= cfail;
@@ -1257,11 +1257,11 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
     int hb = 0;
     if (lane < 3 * MAXHH) hv = (&L.hn_s[0][0])[lane];
     if (lane < MAXHH) hb = L.hb1_s[lane];
-    __syncthreads();
+    wsync<NW>();
     if (lane < 3 * MAXHH) (&L.hn[0][0])[lane] = hv;
     if (lane < MAXHH) L.hb1[lane] = hb;
   }
-  __syncthreads();
+  wsync<NW>();
   qas = lane < NV ? park[lane] : T(0);
   qfs = lane < NV ? park[NV + lane] : T(0);
   asm volatile("" ::"v"(qas), "v"(qfs)); // (the reload is the definition the rest of the kernel uses)
@@ -1328,7 +1328,7 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
   T Ma = 0; // M qacc at the current point
   if (nefc > 0) {
     // helpers over a candidate qacc held per lane (value `xa`, also staged in L.xv)
-    auto stage = [&](T xa) { __syncthreads(); if (lane < NV) L.xv[lane] = xa; __syncthreads(); };
+    auto stage = [&](T xa) { wsync<NW>(); if (lane < NV) L.xv[lane] = xa; wsync<NW>(); };
     auto jar_of = [&](T xa) { // fills rs.fjar / rs.cjar from L.xv
       if (rs.has_f) rs.fjar = xa - rs.faref;
       if (rs.has_c) {
@@ -1433,7 +1433,7 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
         }
         L.cfv[lane][0] = fv[0]; L.cfv[lane][1] = fv[1]; L.cfv[lane][2] = fv[2];
       }
-      __syncthreads();
+      wsync<NW>();
       // ---- gradient: Ma - qfrc_smooth - J^T force
       T grad = 0;
       if (lane < NV) {
@@ -1521,7 +1521,7 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
             }
         }
       }
-      __syncthreads();
+      wsync<NW>();
       // composite contact inertia K[a] = sum of the contact inertias of every body in a's subtree.  Contacts arrive grouped
       // by body.  Stage 1: lane e sums entry e over each group, in place (the group's first contact keeps the sum).  Stage 2:
       // the 21 NB entries of K are dealt to the lanes, each adds up the groups whose body has `a` among its ancestors -
@@ -1544,7 +1544,7 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
           }
         }
       }
-      __syncthreads();
+      wsync<NW>();
       for (int id = lane; id < NB * 21; id += WAVE) {
         const int a = id / 21, e = id - 21 * a;
         T acc = 0;
@@ -1555,7 +1555,7 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
         L.K[a][e] = acc;
       }
       // (K sits in the tree-pass scratch, Wc in the H region: H is written only after the barrier below)
-      __syncthreads();
+      wsync<NW>();
       T Gk[6] = {0, 0, 0, 0, 0, 0};
       const bool mine = lane < NV && ((touched >> (lane < 6 ? 0 : lane - 5)) & 1u);
       if (mine) { // G = K[body of dof k] S_k, before Wc's space becomes H
@@ -1568,9 +1568,9 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
           Gk[i] = sacc;
         }
       }
-      __syncthreads();
+      wsync<NW>();
       for (int i = lane; i < NV * LDM; i += WAVE) L.H[i] = L.M[i];
-      __syncthreads();
+      wsync<NW>();
       if (mine) { // H[i][k] = H[k][i] = M[i][k] + S_i . G_k for the dofs i <= k on k's root path: written once, by lane k alone
         const int k = lane;
         for (unsigned mk = L.anc[lane < 6 ? 0 : lane - 5]; mk; mk &= mk - 1) { // (from LDS: the register copy would be spilled)
@@ -1587,9 +1587,9 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
           }
         }
       }
-      __syncthreads();
+      wsync<NW>();
       if (fact) L.H[lane * LDM + lane] += rs.fD;
-      __syncthreads();
+      wsync<NW>();
       // robot<->robot contacts (rare): H += J^T A J with J = the contact point's relative velocity per unit dof
       // rate (3 x 26, column k on lane k) and A = sum over the active rows of D dir dir^T (3 x 3, held by the
       // contact's lane).  Done on the LDS copy of H, before its rows go to registers: g_k = A j_k is staged in the
@@ -1618,7 +1618,7 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
             g[4] = sgn == 0 ? T(0) : (sgn > 0 ? T(1) : T(-1)) * (hn[0] * L.S[lane][3] + hn[1] * L.S[lane][4] + hn[2] * L.S[lane][5]);
           }
         }
-        __syncthreads();
+        wsync<NW>();
         const T te = rdlane_dyn(tors_e, c), tf = rdlane_dyn(tors_f, c);
         if (lane < NV) {
           const T *g = &L.K[0][0];
@@ -1628,7 +1628,7 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
             for (int k = 0; k < NV; k++) L.H[lane * LDM + k] += te * (ai * g[5 * k + 4] + bi * g[5 * k + 3]) + tf * bi * g[5 * k + 4];
           }
         }
-        __syncthreads();
+        wsync<NW>();
       }
       TSIDB_LAP(25);
       if (hh_cross) { // rare: the dense variant (out of line as well)
@@ -1688,7 +1688,7 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
     }
     solver_iter = iter;
   }
-  __syncthreads();
+  wsync<NW>();
   TSIDB_STAMP(21);
   // ---- semi-implicit Euler, write back
   asm volatile("" ::: "memory");
@@ -1698,7 +1698,7 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
     // MuJoCo's Euler integrates joint damping implicitly: v+ = v + h (M + h B)^-1 (M qacc), with M qacc = the total
     // force the solver ended on (tracked in Ma); qacc itself (reported, warm start) stays the solver's
     T Mq = Ma;
-    if (nefc == 0) { __syncthreads(); if (lane < NV) L.xv[lane] = qacc; __syncthreads(); Mq = mulM(L, L.xv, lane); }
+    if (nefc == 0) { wsync<NW>(); if (lane < NV) L.xv[lane] = qacc; wsync<NW>(); Mq = mulM(L, L.xv, lane); }
 #pragma unroll
     for (int j = 0; j < NV; j++) arow[j] = lane < NV ? L.M[lane * LDM + j] + (j == lane ? dte * m.mj_damping[j] : T(0)) : T(0);
     bool okd;
@@ -1712,7 +1712,7 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
     qacc_ws_g[lane] = qacc;
     if (qacc_out) qacc_out[lane] = qacc;
   }
-  __syncthreads();
+  wsync<NW>();
   if (lane < 3) L.qpos[lane] += dte * L.qvel[lane];
   if (lane >= 6 && lane < NV) L.qpos[lane + 1] += dte * L.qvel[lane];
   if (lane == 3) {
@@ -1735,7 +1735,7 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
 #pragma unroll
     for (int i = 0; i < 4; i++) L.qpos[3 + i] = r[i] * nn;
   }
-  __syncthreads();
+  wsync<NW>();
   if (lane < NQ) qpos_g[lane] = L.qpos[lane];
   if (lane == 0 && info) { info[2] = solver_iter; info[3] = fail; }
   TSIDB_STAMP(22);

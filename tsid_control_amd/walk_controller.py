@@ -12,6 +12,7 @@ TaskActuationBounds, TaskJointBounds, SolverHQuadProgFast.  The `formulation`, `
 objects of the reference have no counterpart - their work happens inside `step()`.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -85,7 +86,7 @@ class WalkController:
         rc = L.tsidb_set_refs(self._h, _ptr(self.com_ref), _ptr(self.posture_ref), _ptr(self.foot_ref),
                               _ptr(self.contact_ref), _ptr(self.contact_active), _ptr(self.cop_frames))
         _lib.check(L, self._h, rc, "tsidb_set_refs")
-        sw = int(getattr(conf, "sim_waves", 0))   # 0 = the library's choice (2 wavefronts per env up to 640 envs, else 1)
+        sw = int(getattr(conf, "sim_waves", 0))   # 0 = the library's choice (2 wavefronts per env up to 384 envs, else 1)
         if sw:
             _lib.check(L, self._h, L.tsidb_set_option(self._h, 1, sw), "tsidb_set_option(sim_waves)")
         self.cop_ref = z(N, 3)   # reference of the CoP force task (legacy/biped.py:79-80; conf.w_cop)
@@ -102,7 +103,7 @@ class WalkController:
         b = int(getattr(conf, "pipeline_sim_batch", 0))
         # 0 = auto: small batches are latency bound, there the barrier packets of the per-step cross-stream handshake are
         # 15-20 % of a step (measured: 512 envs +7 %, 1024 +5 %, 2048 and up nothing / noise)
-        self.sim_batch = b if b > 0 else (4 if self.num_envs <= 1024 else 1)   # step_pipelined(): sim stages enqueued this many at a time
+        self.sim_batch = min(8, b) if b > 0 else (8 if self.num_envs <= 1024 else 1)   # step_pipelined(): sim stages enqueued this many at a time (one launch: tsidb_sim_batch)
         self.reset()
         self.q0 = self.q.clone()  # WalkController.py:23 (after the z shift of :74, which aliases q0)
 
@@ -280,9 +281,11 @@ class WalkController:
             # ring of snapshot slots: the tick writes its slot itself, so it must wait for the sim that read the slot
             # K steps ago BEFORE it starts - with only two slots that wait held tick(t) back until sim(t - 2) was done
             # and cost 12 % at 4096 envs; four slots and the tick stream runs ahead as before
-            K = max(4, 2 * self.sim_batch)
-            self._pipe = dict(stream=torch.cuda.Stream(device=self.device), par=0, done=[None] * K, pending=[],
-                              q=[torch.empty_like(self.q) for _ in range(K)], v=[torch.empty_like(self.v) for _ in range(K)])
+            K = max(4, int(os.environ.get("TSIDB_RING_SLOTS", "0")) or 2 * self.sim_batch)
+            qring = torch.empty(K, *self.q.shape, dtype=self.dtype, device=self.device)   # one allocation: a batch of sim
+            vring = torch.empty(K, *self.v.shape, dtype=self.dtype, device=self.device)   # stages names its slots by number
+            self._pipe = dict(stream=torch.cuda.Stream(device=self.device), par=0, done=[None] * K, pending=[], qring=qring, vring=vring,
+                              q=[qring[k] for k in range(K)], v=[vring[k] for k in range(K)])
         P = self._pipe
         par = P["par"]
         P["par"] = (par + 1) % len(P["q"])
@@ -375,18 +378,34 @@ class WalkController:
         ready.record(cur)
         with torch.cuda.stream(P["stream"]):
             P["stream"].wait_event(ready)
-            for i, slot in enumerate(P["pending"]):
-                last = i == len(P["pending"]) - 1
-                if events and last:
-                    events[2].record(P["stream"])
-                self.sim_step(q_tsid=P["q"][slot], v_tsid=P["v"][slot], _from_pipe=True)
-                if events and last:
-                    events[3].record(P["stream"])
+            pend = list(P["pending"])
+            if events:                       # timing events bracket the last sim step alone
+                head, pend = pend[:-1], pend[-1:]
+                if head:
+                    self._sim_batch(head)
+                events[2].record(P["stream"])
+            self._sim_batch(pend)
+            if events:
+                events[3].record(P["stream"])
             done = torch.cuda.Event()
             done.record(P["stream"])
         for slot in P["pending"]:
             P["done"][slot] = done
         P["pending"] = []
+
+    def _sim_batch(self, slots):
+        """the sim stages of several ticks in ONE launch (tsidb_sim_batch): each env steps len(slots) times, teleporting to
+        the snapshot of its tick each time - no launch gaps between the steps"""
+        B = len(slots)
+        if B == 1:
+            self.sim_step(q_tsid=self._pipe["q"][slots[0]], v_tsid=self._pipe["v"][slots[0]], _from_pipe=True)
+            return
+        sl = (C.c_int32 * B)(*slots)
+        with torch.cuda.device(self.device):
+            rc = self._L.tsidb_sim_batch(self._h, B, _ptr(self._pipe["qring"]), _ptr(self._pipe["vring"]), sl, _ptr(self.qpos),
+                                         _ptr(self.qvel), _ptr(self.qacc_warmstart), None, _ptr(self.ncon), _ptr(self.con_pairs),
+                                         _ptr(self.info), self._stream())
+        _lib.check(self._L, self._h, rc, "tsidb_sim_batch")
 
     def sync_sim(self):
         """Make the current stream wait for the sim stages step_pipelined() left in flight (or not yet enqueued)."""
