@@ -299,7 +299,10 @@ def test_v0_sim_step_matches_oracle_on_gpu(v0):
             assert np.array_equal(wc.con_pairs[e].cpu().numpy(), want), (i, e)
             assert r["flags"] == int(wc.info[e, 3]) & (8 | 16 | 32)
             n_hh += int((r["con_body1"] >= 0).sum()); n_fl += int((r["con_body1"] < 0).sum())
-        assert d(wc.qpos, qpos) < 1e-7 and d(wc.qvel, qvel) < 1e-4, i
+        # (round 3: the Newton solver keeps its factor across iterations - rank-1 row updates, tree-sparse on the device and
+        #  dense in the oracle - so the two converge to the solver tolerance along slightly different iterates; over 40 steps
+        #  of tumbling, self-penetrating robots that grows to ~1e-7 in qpos: 5e-7 here, contact lists stay bit-exact)
+        assert d(wc.qpos, qpos) < 5e-7 and d(wc.qvel, qvel) < 1e-4, i
     assert n_hh > 200 and n_fl > 1000 and bool(torch.isfinite(wc.qpos).all())
     # joint targets beyond ctrlrange (robot.xml:5), in the air: the reference loop's teleport + ctrl map + step (main.py:192-195)
     wc2 = WalkController(v0["conf"], num_envs=n, device="cuda:0")

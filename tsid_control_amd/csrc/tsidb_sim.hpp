@@ -366,6 +366,53 @@ __device__ __forceinline__ void contact_rows(const DevModel<T> &m, const SimLds<
   }
 }
 
+// the same for K generalized vectors at once: ONE walk over the contact's body chains (the motion vectors S are read once),
+// K twists side by side.  Used where the rows are needed for several vectors from the same state: joint velocities (the
+// reference acceleration), the warm start and the unconstrained acceleration - three walks before.
+template <typename T, int K>
+__device__ __forceinline__ void contact_rows_multi(const DevModel<T> &m, const SimLds<T> &L, int nfl, int c, const T *const (&x)[K],
+                                                   T mu, T (&out)[K][NROWC]) {
+  T n[3], t1[3], t2[3];
+  const int b1 = contact_frame(L, c, nfl, n, t1, t2);
+  T tw[K][6];
+#pragma unroll
+  for (int k = 0; k < K; k++)
+#pragma unroll
+    for (int i = 0; i < 6; i++) tw[k][i] = 0;
+  const unsigned m2 = L.anc[L.cbody[c]], m1 = b1 >= 0 ? L.anc[b1] : 0u;
+#pragma unroll
+  for (int side = 0; side < 2; side++) {
+    const T sg = side == 0 ? T(1) : T(-1);
+    for (unsigned mk = side == 0 ? (m2 & ~m1) : (m1 & ~m2); mk; mk &= mk - 1) {
+      const int a = __ffs(mk) - 1;
+      const int d0 = a == 0 ? 0 : 5 + a, d1 = a == 0 ? 5 : 5 + a;
+      for (int d = d0; d <= d1; d++) {
+        T Sd[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) Sd[i] = L.S[d][i];
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+          const T xk = sg * x[k][d];
+#pragma unroll
+          for (int i = 0; i < 6; i++) tw[k][i] += Sd[i] * xk;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < K; k++) {
+    T wxr[3];
+    cross3(tw[k] + 3, L.cr[c], wxr);
+    const T u[3] = {tw[k][0] + wxr[0], tw[k][1] + wxr[1], tw[k][2] + wxr[2]};
+    const T un = dot3(n, u), u1 = dot3(t1, u), u2 = dot3(t2, u);
+    out[k][0] = un + mu * u1; out[k][1] = un - mu * u1; out[k][2] = un + mu * u2; out[k][3] = un - mu * u2;
+    if constexpr (CONDIM > 3) {
+      const T ut = m.contact[9] * dot3(n, tw[k] + 3);
+      out[k][4] = un + ut; out[k][5] = un - ut;
+    }
+  }
+}
+
 // ------------------------------------------------------------------ collision helpers
 // stepped terrain (BASELINE.json configs[4]; no reference counterpart): the floor surface is the plane n.x = d
 // raised along n by heights[cell & 15], cell = floor((dir . x_world_xy - phase) * inv_len).
@@ -1316,10 +1363,9 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
     T R0 = (1 - imp) / imp * diagA;
     R0 = R0 > MINVAL ? R0 : MINVAL;
     rs.cD = T(1) / (2 * mu * mu * R0);
-    T vel[NROWC];
-    contact_rows(m, L, nfl, c, L.qvel, mu, vel);
+    // (reference acceleration of the rows: - bb J v is added below, in the walk that also evaluates the warm start)
 #pragma unroll
-    for (int i = 0; i < NROWC; i++) rs.caref[i] = -bb * vel[i] - kk * imp * (dist - margin);
+    for (int i = 0; i < NROWC; i++) rs.caref[i] = -kk * imp * (dist - margin);
   }
 
   int solver_iter = 0;
@@ -1329,36 +1375,41 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
   if (nefc > 0) {
     // helpers over a candidate qacc held per lane (value `xa`, also staged in L.xv)
     auto stage = [&](T xa) { wsync<NW>(); if (lane < NV) L.xv[lane] = xa; wsync<NW>(); };
-    auto jar_of = [&](T xa) { // fills rs.fjar / rs.cjar from L.xv
-      if (rs.has_f) rs.fjar = xa - rs.faref;
-      if (rs.has_c) {
-        T o[NROWC];
-        contact_rows(m, L, nfl, lane, L.xv, mu, o);
-#pragma unroll
-        for (int i = 0; i < NROWC; i++) rs.cjar[i] = o[i] - rs.caref[i];
-      }
-    };
-    // warm start: keep qacc_warmstart only if it is cheaper than qacc_smooth
+    // warm start: keep qacc_warmstart only if it is cheaper than qacc_smooth.  The contact rows of the joint velocities
+    // (reference acceleration), of the warm start and of qacc_smooth come out of ONE walk over each contact's body chain
+    // (qacc_smooth is still in LDS where it was parked for the collision phase)
     T xw = lane < NV ? qacc_ws_g[lane] : T(0);
     stage(xw);
     Ma = mulM(L, L.xv, lane);
-    jar_of(xw);
+    T cjar_w[NROWC], cjar_s[NROWC];
+#pragma unroll
+    for (int i = 0; i < NROWC; i++) cjar_w[i] = cjar_s[i] = 0;
+    if (rs.has_c) {
+      const T *const xs[3] = {L.qvel, L.xv, park};
+      T o[3][NROWC];
+      contact_rows_multi<T, 3>(m, L, nfl, lane, xs, mu, o);
+#pragma unroll
+      for (int i = 0; i < NROWC; i++) {
+        rs.caref[i] -= bb * o[0][i];
+        cjar_w[i] = o[1][i] - rs.caref[i];
+        cjar_s[i] = o[2][i] - rs.caref[i];
+      }
+    }
+    const T fjar_w = rs.has_f ? xw - rs.faref : T(0), fjar_s = rs.has_f ? qas - rs.faref : T(0);
     T cc, gg, hh;
+    rs.fjar = fjar_w;
+#pragma unroll
+    for (int i = 0; i < NROWC; i++) rs.cjar[i] = cjar_w[i];
     rows_eval(rs, T(0), cc, gg, hh);
     T cost_w = wave_sum(cc + (lane < NV ? T(0.5) * (Ma - qfs) * (xw - qas) : T(0)));
-    // keep the warm start's row residuals while the smooth solution is evaluated: whichever wins, its
-    // M a and residuals are already there (same operations on the same data as evaluating the winner again)
-    const T fjar_w = rs.fjar;
-    T cjar_w[NROWC];
+    rs.fjar = fjar_s;
 #pragma unroll
-    for (int i = 0; i < NROWC; i++) cjar_w[i] = rs.cjar[i];
-    stage(qas);
-    jar_of(qas);
+    for (int i = 0; i < NROWC; i++) rs.cjar[i] = cjar_s[i];
     rows_eval(rs, T(0), cc, gg, hh);
     T cost_s = wave_sum(cc);
     if (cost_w > cost_s) {
       qacc = qas;
-      Ma = mulM(L, L.xv, lane); // L.xv still holds qacc_smooth
+      Ma = mulM(L, park, lane); // M qacc_smooth
     } else {
       qacc = xw;
       rs.fjar = fjar_w;
