@@ -64,6 +64,8 @@ struct TickLds {
   T com[3], vcom[3], acomd[3];
   T Lam[3], dLam[3]; // centroidal angular momentum and its drift (angular-momentum task)
   T qs[NQ], vs[NV];
+  int act[2]; // contact flags of this tick (LF, RF): read where needed - kept in registers from the top of the tick they are
+              // long-lived values the QP phases have no room for (they were spilled to scratch)
 };
 static_assert(sizeof(ActiveSetLds<double>) <= sizeof(KinScratch<double>), "active-set state must fit the scratch region");
 static_assert(sizeof(TickLds<double>) <= 20480, "k_tick must fit 8 workgroups per CU");
@@ -350,9 +352,14 @@ __device__ __forceinline__ int rcol(int c) { return c * (c + 1) / 2; } // packed
 template <typename T>
 struct QpCtx {
   int n, nslot, nin, p, iq;
-  int slot_foot[2];
   T R_norm;
 };
+// foot carried by contact slot s of a tick with NS feet in contact (slots are LF, RF in that order)
+template <typename T, int NS> __device__ __forceinline__ int slot_foot(const TickLds<T> &L, int s) {
+  if constexpr (NS == 2) return s;
+  else if constexpr (NS == 1) return L.act[0] ? 0 : 1;
+  else return -1;
+}
 
 // One-sided inequality rows (CI x + ci0 >= 0), ordered as tsid stacks them: per contact slot 17 cone
 // lower + 17 cone upper rows, then 20 + 20 actuation rows, then 26 + 26 acceleration-bound rows.
@@ -767,7 +774,7 @@ __device__ __forceinline__ void tick_qp(const DevModel<T> &m, TickLds<T> &L, QpC
       T yv = 0;
       // CE row `col`: base dynamics rows come from Dyn, contact motion rows from the frame Jacobians
       const bool isbase = col < 6;
-      const int crow = col < 6 ? col : 6 * c.slot_foot[(col - 6) / 6] + (col - 6) % 6;
+      const int crow = col < 6 ? col : 6 * slot_foot<T, NS>(L, (col - 6) / 6) + (col - 6) % 6;
 #pragma unroll
       for (int i = 0; i < NV; i++) {
         const T rdi = rdlane(rdv, i); // 1 / L[i][i] (lane i keeps it: 26 wave-uniform doubles held across these loops
@@ -800,7 +807,7 @@ __device__ __forceinline__ void tick_qp(const DevModel<T> &m, TickLds<T> &L, QpC
       c2 = wave_sum(c2) + T(c.nslot) * m.Jf0_trace;
       if (bl) {
         if (col < 6) ck += L.h[col];
-        else ck -= L.k.arhs[c.slot_foot[(col - 6) / 6]][(col - 6) % 6];
+        else ck -= L.k.arhs[slot_foot<T, NS>(L, (col - 6) / 6)][(col - 6) % 6];
       }
       // rows of the dv block go to their group's lane
 #pragma unroll
@@ -854,7 +861,7 @@ __device__ __forceinline__ void tick_qp(const DevModel<T> &m, TickLds<T> &L, QpC
           const T tiny = sizeof(T) == 8 ? T(1e-30) : T(1e-20);
           T A0 = 0, A1 = 0;
           if (isf) {
-            const int sl = fcol / 12, pt = (fcol % 12) / 3, j = fcol % 3, f = c.slot_foot[sl];
+            const int sl = fcol / 12, pt = (fcol % 12) / 3, j = fcol % 3, f = slot_foot<T, NS>(L, sl);
             const T *R = L.oMf[f], *pp = L.oMf[f] + 9;
             const T *r = &m.params[P_CPOINTS + 3 * pt];
             T d[3], x1[3], x2[3];
@@ -1092,6 +1099,7 @@ __device__ __forceinline__ void tsid_tick_env(const DevModel<T> &m, TickLds<T> &
     if (lane < NQ) L.qs[lane] = q[lane];
     if (lane < NV) L.vs[lane] = v[lane];
   }
+  if (lane >= 32 && lane < 34) L.act[lane - 32] = cact[lane - 32] != 0; // (the caller dispatched on act[0] + act[1] == NS)
   __syncthreads();
   rbd_terms(m, L, lane);
   if (m.params[P_TSID_ARMATURE] != 0) { // closed-loop knob: rotor inertia of the actuated joints in TSID's model
@@ -1101,10 +1109,7 @@ __device__ __forceinline__ void tsid_tick_env(const DevModel<T> &m, TickLds<T> &
   TSIDB_STAMP(1);
 
   QpCtx<T> c;
-  const int act0 = cact[0] != 0, act1 = cact[1] != 0; // the caller dispatched on act0 + act1 == NS
   c.nslot = NS;
-  c.slot_foot[0] = NS == 2 ? 0 : (NS == 1 ? (act0 ? 0 : 1) : -1);
-  c.slot_foot[1] = NS == 2 ? 1 : -1;
   c.n = NV + 12 * NS;
   c.p = 6 + 6 * NS;
   c.nin = 34 * NS + 2 * NA + 2 * NV;
@@ -1128,7 +1133,7 @@ __device__ __forceinline__ void tsid_tick_env(const DevModel<T> &m, TickLds<T> &
   }
   // ---- right block of the dynamics rows: Dyn[r][26 + 12 s + cc] = -sum_i T[i][cc] Jf[6 f + i][r]
   for (int idx = lane; idx < NV * 12 * c.nslot; idx += WAVE) {
-    const int r = idx / (12 * c.nslot), cc = idx % (12 * c.nslot), s = cc / 12, e = cc % 12, f = c.slot_foot[s];
+    const int r = idx / (12 * c.nslot), cc = idx % (12 * c.nslot), s = cc / 12, e = cc % 12, f = slot_foot<T, NS>(L, s);
     T a = 0;
 #pragma unroll
     for (int i = 0; i < 6; i++) a += m.Tgen[i][e] * L.k.Jf[(6 * f + i) * LDF + r];
@@ -1256,7 +1261,7 @@ __device__ __forceinline__ void tsid_tick_env(const DevModel<T> &m, TickLds<T> &
     const int fo = lane / 12, e = lane % 12;
     T val = 0;
     for (int s = 0; s < c.nslot; s++)
-      if (solved && c.slot_foot[s] == fo) val = L.x[NV + 12 * s + e];
+      if (solved && slot_foot<T, NS>(L, s) == fo) val = L.x[NV + 12 * s + e];
     fout[lane] = val;
     L.as.s[lane] = val; // staged for the CoP
   }
@@ -1293,7 +1298,7 @@ __device__ __forceinline__ void tsid_tick_env(const DevModel<T> &m, TickLds<T> &
     for (int fo = 0; fo < 2; fo++) {
       const T w2 = rdlane(wl, 6 * fo + 2), w3 = rdlane(wl, 6 * fo + 3), w4 = rdlane(wl, 6 * fo + 4);
       T cl[3] = {0, 0, 0};
-      const bool on = fo == 0 ? act0 : act1;
+      const bool on = L.act[fo] != 0;
       if (on && w2 > T(1e-3)) { cl[0] = w4 / w2; cl[1] = w3 / w2; }
       const T *F = (m.params[P_QUIRKS] != 0 && cop_frames) ? cop_frames + 12 * fo : L.oMf[fo];
 #pragma unroll
@@ -1301,7 +1306,7 @@ __device__ __forceinline__ void tsid_tick_env(const DevModel<T> &m, TickLds<T> &
       fz[fo] = w2;
     }
     T cop[3] = {0, 0, 0};
-    if (act0 && act1 && fz[0] + fz[1] != 0) {
+    if (NS == 2 && fz[0] + fz[1] != 0) {
       cop[0] = (copw[0][0] * fz[0] + copw[1][0] * fz[1]) / (fz[0] + fz[1]);
       cop[1] = (copw[0][1] * fz[0] + copw[1][1] * fz[1]) / (fz[0] + fz[1]);
     }
