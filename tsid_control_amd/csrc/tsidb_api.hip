@@ -613,6 +613,15 @@ void tree_tables(const int *parent, int n, int *depth, int *nchild, int (*child)
     for (int j = 0; j < n; j++) up[r][j] = up[r - 1][j] < 0 ? -1 : up[r - 1][up[r - 1][j]];
 }
 
+// chain[j] = j and its ancestors other than the root, deepest first, -1 padded (tree depth <= 7, checked by tree_tables)
+static void chain_table(const int *parent, int n, int (*chain)[8]) {
+  for (int j = 0; j < n; j++) {
+    int k = 0;
+    for (int i = 0; i < 8; i++) chain[j][i] = -1;
+    for (int a = j; a > 0 && k < 8; a = parent[a]) chain[j][k++] = a;
+  }
+}
+
 } // namespace
 
 struct tsidb_ctx {
@@ -643,6 +652,7 @@ static void build_model(tsidb_ctx *h, DevModel<T> &m) {
   // ---- TSID side
   memcpy(m.pin_parent, b.i32("pin_parent", NJ), sizeof m.pin_parent);
   tree_tables(m.pin_parent, NJ, m.pin_depth, m.pin_nchild, m.pin_child, m.pin_anc, &m.pin_maxdepth, m.pin_last, m.pin_up);
+  chain_table(m.pin_parent, NJ, m.pin_chain);
   const double *pl = b.f64("pin_place", NJ * 12), *in = b.f64("pin_inertia", NJ * 10);
   double mass = 0;
   for (int j = 0; j < NJ; j++) {
@@ -735,6 +745,7 @@ static void build_model(tsidb_ctx *h, DevModel<T> &m) {
       throw std::string("model blob's sim tree differs from the topology this library was compiled for "
                         "(regenerate csrc/tsidb_topology.hpp with model_compiler.py and rebuild)");
   tree_tables(m.mj_parent, NB, m.mj_depth, m.mj_nchild, m.mj_child, m.mj_anc, &m.mj_maxdepth, m.mj_last, m.mj_up);
+  chain_table(m.mj_parent, NB, m.mj_chain);
   const double *mp = b.f64("mj_pos", NB * 3), *mq = b.f64("mj_quat", NB * 4), *mi = b.f64("mj_inertia", NB * 10);
   for (int j = 0; j < NB; j++) {
     double R[9];

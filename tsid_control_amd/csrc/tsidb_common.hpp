@@ -68,6 +68,8 @@ struct DevModel {
   unsigned pin_anc[NJ]; // bit a set <=> joint a is an ancestor of (or is) joint j
   int pin_last[NJ];     // last index of joint j's subtree (depth-first pre-order numbering)
   int pin_up[3][NJ];    // ancestor 1, 2, 4 levels up (-1 beyond the root)
+  int pin_chain[NJ][8]; // the joint itself and its non-root ancestors, deepest first, -1 padded (the root is on every chain):
+                        // static, fully unrolled walks over a dof's root path instead of bit-mask loops with dependent loads
   int pin_maxdepth;
   T pin_place[NJ][12];   // R row-major, p
   T pin_inertia[NJ][10]; // m, c(3), Ixx Ixy Ixz Iyy Iyz Izz about c
@@ -88,6 +90,7 @@ struct DevModel {
   unsigned mj_anc[NB];
   int mj_last[NB];
   int mj_up[3][NB];
+  int mj_chain[NB][8];
   int mj_maxdepth;
   T mj_pos[NB][3], mj_R[NB][9]; // body frame in parent (rotation from body_quat)
   T mj_inertia[NB][10];
@@ -357,11 +360,11 @@ template <typename T> __device__ __forceinline__ void cross_mf(const T *v, const
 // the joint's motion vector S (non-root), V, A of every node.
 //   transforms : pointer jumping - round r composes each node with its ancestor 2^r levels up (tables
 //                up0/up1/up2, -1 beyond the root), three rounds instead of one LDS round trip per level
-//   V, A       : sums over the ancestors (bitmask) of S qd and of V x (S qd), which only add in this
-//                representation
+//   V, A       : sums over the node's root path (chain table: the node and its non-root ancestors) of S qd and of
+//                V x (S qd), which only add in this representation
 // bufA / bufB: two n*12 scratch areas, sq / cb: n rows of >= 6 (strides given), all in LDS.
 template <typename T>
-__device__ __forceinline__ void tree_forward(int lane, int n, int up0, int up1, int up2, unsigned ancmask, T *bufA, T *bufB,
+__device__ __forceinline__ void tree_forward(int lane, int n, int up0, int up1, int up2, const int (&chn)[7], T *bufA, T *bufB,
                                              T *sq, int sq_stride, T *cb, int cb_stride, T (&R)[9], T (&p)[3], T qd,
                                              T (&S)[6], T (&V)[6], T (&A)[6]) {
   const bool on = lane < n;
@@ -419,11 +422,16 @@ __device__ __forceinline__ void tree_forward(int lane, int n, int up0, int up1, 
   __syncthreads();
   if (on && lane > 0) {
 #pragma unroll
-    for (int i = 0; i < 6; i++) V[i] = 0;
-    for (unsigned mk = ancmask; mk; mk &= mk - 1) {
-      const int a = __ffs(mk) - 1;
+    for (int i = 0; i < 6; i++) V[i] = sq[i]; // the root, then the node's chain from the shallowest ancestor down to itself:
+                                              // a static walk (chain table), every load independent - the ancestor
+                                              // bit-mask loop waited out one LDS round trip per level; same order of sums
 #pragma unroll
-      for (int i = 0; i < 6; i++) V[i] += sq[a * sq_stride + i];
+    for (int d = 6; d >= 0; d--) {
+      const int a = chn[d];
+      if (a > 0) {
+#pragma unroll
+        for (int i = 0; i < 6; i++) V[i] += sq[a * sq_stride + i];
+      }
     }
   }
   T cj[6];
@@ -439,11 +447,14 @@ __device__ __forceinline__ void tree_forward(int lane, int n, int up0, int up1, 
   __syncthreads();
   if (on && lane > 0) {
 #pragma unroll
-    for (int i = 0; i < 6; i++) A[i] = 0;
-    for (unsigned mk = ancmask; mk; mk &= mk - 1) {
-      const int a = __ffs(mk) - 1;
+    for (int i = 0; i < 6; i++) A[i] = cb[i];
 #pragma unroll
-      for (int i = 0; i < 6; i++) A[i] += cb[a * cb_stride + i];
+    for (int d = 6; d >= 0; d--) {
+      const int a = chn[d];
+      if (a > 0) {
+#pragma unroll
+        for (int i = 0; i < 6; i++) A[i] += cb[a * cb_stride + i];
+      }
     }
   }
   __syncthreads(); // sq / cb / bufA / bufB are free again

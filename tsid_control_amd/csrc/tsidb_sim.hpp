@@ -967,7 +967,6 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
   const int up0 = lane < NB ? m.mj_up[0][lane] : -1, up1 = lane < NB ? m.mj_up[1][lane] : -1,
             up2 = lane < NB ? m.mj_up[2][lane] : -1;
   const unsigned bodyanc = lane < NB ? m.mj_anc[lane] : 0u;
-  const unsigned dofanc = lane < NV ? m.mj_anc[lane < 6 ? 0 : lane - 5] : 0u;
   if (lane < NB) L.anc[lane] = bodyanc;
 #pragma unroll
   for (int i = 0; i < 6; i++) { Vb[i] = 0; Ab[i] = 0; Sb[i] = 0; }
@@ -1011,7 +1010,10 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
       pb[i] = m.mj_pos[lane][i];
     }
   }
-  tree_forward<T>(lane, NB, up0, up1, up2, bodyanc, &L.R[0][0], &L.V[0][0], &L.f[0][0], 6, &L.Yc[0][0], 10, Rb, pb, qd, Sb,
+  int bchn[7];
+#pragma unroll
+  for (int d = 0; d < 7; d++) bchn[d] = lane < NB ? m.mj_chain[lane][d] : -1;
+  tree_forward<T>(lane, NB, up0, up1, up2, bchn, &L.R[0][0], &L.V[0][0], &L.f[0][0], 6, &L.Yc[0][0], 10, Rb, pb, qd, Sb,
                   Vb, Ab);
   if (lane < NB) {
     const int b = lane;
@@ -1079,17 +1081,20 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
 #pragma unroll
     for (int i = 0; i < 6; i++) { Sk[i] = L.S[k][i]; hk += Sk[i] * L.f[bk][i]; }
     yo_mul(L.Yc[bk], Sk, Fk);
-    for (unsigned mk = dofanc; mk; mk &= mk - 1) {
-      const int a = __ffs(mk) - 1;
-      const int i0 = a == 0 ? 0 : 5 + a, i1 = a == 0 ? 5 : 5 + a;
-      for (int i = i0; i <= i1; i++) {
-        if (i > k) continue;
-        T val = 0;
+    // (a static walk over the chain table - the body's non-root ancestors, then the root's six dofs: every load independent
+    //  and issued up front, where the bit-mask loop waited out one LDS round trip per ancestor)
+    int chn[7];
 #pragma unroll
-        for (int e = 0; e < 6; e++) val += L.S[i][e] * Fk[e];
-        L.M[i * LDM + k] = val;
-        L.M[k * LDM + i] = val;
-      }
+    for (int d = 0; d < 7; d++) chn[d] = m.mj_chain[bk][d];
+#pragma unroll
+    for (int d = 0; d < 7 + 6; d++) {
+      const int i = d < 7 ? (chn[d < 7 ? d : 0] > 0 ? 5 + chn[d < 7 ? d : 0] : -1) : d - 7;
+      if (i < 0 || i > k) continue;
+      T val = 0;
+#pragma unroll
+      for (int e = 0; e < 6; e++) val += L.S[i][e] * Fk[e];
+      L.M[i * LDM + k] = val;
+      L.M[k * LDM + i] = val;
     }
     qfs = -hk;
   }
@@ -1623,19 +1628,20 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
       for (int i = lane; i < NV * LDM; i += WAVE) L.H[i] = L.M[i];
       wsync<NW>();
       if (mine) { // H[i][k] = H[k][i] = M[i][k] + S_i . G_k for the dofs i <= k on k's root path: written once, by lane k alone
-        const int k = lane;
-        for (unsigned mk = L.anc[lane < 6 ? 0 : lane - 5]; mk; mk &= mk - 1) { // (from LDS: the register copy would be spilled)
-          const int a = __ffs(mk) - 1;
-          const int i0 = a == 0 ? 0 : 5 + a, i1 = a == 0 ? 5 : 5 + a;
-          for (int i = i0; i <= i1; i++) {
-            if (i > k) continue;
-            T val = 0;
+        const int k = lane, bk = k < 6 ? 0 : k - 5;
+        int chn[7];
 #pragma unroll
-            for (int e = 0; e < 6; e++) val += L.S[i][e] * Gk[e];
-            const T hv = L.M[i * LDM + k] + val;
-            L.H[i * LDM + k] = hv;
-            L.H[k * LDM + i] = hv;
-          }
+        for (int d = 0; d < 7; d++) chn[d] = m.mj_chain[bk][d];
+#pragma unroll
+        for (int d = 0; d < 7 + 6; d++) { // (static walk over the chain table, as for M)
+          const int i = d < 7 ? (chn[d < 7 ? d : 0] > 0 ? 5 + chn[d < 7 ? d : 0] : -1) : d - 7;
+          if (i < 0 || i > k) continue;
+          T val = 0;
+#pragma unroll
+          for (int e = 0; e < 6; e++) val += L.S[i][e] * Gk[e];
+          const T hv = L.M[i * LDM + k] + val;
+          L.H[i * LDM + k] = hv;
+          L.H[k * LDM + i] = hv;
         }
       }
       wsync<NW>();

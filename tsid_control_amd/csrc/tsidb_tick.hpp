@@ -100,8 +100,9 @@ __device__ __forceinline__ void rbd_terms(const DevModel<T> &m, TickLds<T> &L, i
   // topology into registers up front: no dependent global loads inside the tree passes
   const int up0 = lane < NJ ? m.pin_up[0][lane] : -1, up1 = lane < NJ ? m.pin_up[1][lane] : -1,
             up2 = lane < NJ ? m.pin_up[2][lane] : -1;
-  const unsigned jointanc = lane < NJ ? m.pin_anc[lane] : 0u;
-  const unsigned dofanc = lane < NV ? m.pin_anc[lane < 6 ? 0 : lane - 5] : 0u; // ancestors of this dof's joint
+  int jchn[7];
+#pragma unroll
+  for (int d = 0; d < 7; d++) jchn[d] = lane < NJ ? m.pin_chain[lane][d] : -1;
 #pragma unroll
   for (int i = 0; i < 6; i++) { Vj[i] = 0; Aj[i] = 0; Sj[i] = 0; }
 #pragma unroll
@@ -136,7 +137,7 @@ __device__ __forceinline__ void rbd_terms(const DevModel<T> &m, TickLds<T> &L, i
     }
   }
   TSIDB_LAP(15);
-  tree_forward<T>(lane, NJ, up0, up1, up2, jointanc, &K.R[0][0], &K.V[0][0], &K.f[0][0], 6, &K.Yc[0][0], 10, Rj, pj, qd, Sj,
+  tree_forward<T>(lane, NJ, up0, up1, up2, jchn, &K.R[0][0], &K.V[0][0], &K.f[0][0], 6, &K.Yc[0][0], 10, Rj, pj, qd, Sj,
                   Vj, Aj);
   if (lane < NJ) {
     const int j = lane;
@@ -215,18 +216,21 @@ __device__ __forceinline__ void rbd_terms(const DevModel<T> &m, TickLds<T> &L, i
     ja[0] = Fk[3] - (cy * Fk[2] - cz * Fk[1]);
     ja[1] = Fk[4] - (cz * Fk[0] - cx * Fk[2]);
     ja[2] = Fk[5] - (cx * Fk[1] - cy * Fk[0]);
-    // M[i][k] = S_i . F_k for every dof i on the path root..k (ancestor bitmask; loads independent)
-    for (unsigned mk = dofanc; mk; mk &= mk - 1) {
-      const int a = __ffs(mk) - 1;
-      const int i0 = a == 0 ? 0 : 5 + a, i1 = a == 0 ? 5 : 5 + a;
-      for (int i = i0; i <= i1; i++) {
-        if (i > k) continue;
-        T val = 0;
+    // M[i][k] = S_i . F_k for every dof i on the path root..k: a static walk over the chain table (the joint's non-root
+    // ancestors, then the root's six dofs) - every load is independent and issued up front; the bit-mask loop it replaces
+    // waited out one LDS round trip per ancestor
+    int chn[7];
 #pragma unroll
-        for (int e = 0; e < 6; e++) val += K.S[i][e] * Fk[e];
-        L.Dyn[i * LDD + k] = val;
-        L.Dyn[k * LDD + i] = val;
-      }
+    for (int d = 0; d < 7; d++) chn[d] = m.pin_chain[jk][d];
+#pragma unroll
+    for (int d = 0; d < 7 + 6; d++) {
+      const int i = d < 7 ? (chn[d < 7 ? d : 0] > 0 ? 5 + chn[d < 7 ? d : 0] : -1) : d - 7;
+      if (i < 0 || i > k) continue;
+      T val = 0;
+#pragma unroll
+      for (int e = 0; e < 6; e++) val += K.S[i][e] * Fk[e];
+      L.Dyn[i * LDD + k] = val;
+      L.Dyn[k * LDD + i] = val;
     }
   }
   TSIDB_LAP(31);
@@ -990,7 +994,10 @@ __device__ __forceinline__ void tick_qp(const DevModel<T> &m, TickLds<T> &L, QpC
           // the reflector is READ AGAIN from lane k's registers: left to itself the compiler keeps the first loop's
           // NN broadcast values (2 SGPRs each) for this loop, i.e. spills them to VGPR lanes with v_writelane and
           // reloads them with v_readlane - three times the instructions of reading them again, and the spill lanes
-          // were what pushed the kernel over its VGPR budget (3 800 SGPR spills -> see DESIGN.md section 4)
+          // were what pushed the kernel over its VGPR budget (3 800 SGPR spills -> see DESIGN.md section 4).
+          // (Round 3, measured and dropped: the reflector staged in LDS by the lanes that hold it and read back at wave-uniform
+          //  addresses, 8 entries per chunk with the next chunk's reads in flight - 1560 v_readlane less on paper; the unrolled
+          //  k loop outgrew the pragma-unroll threshold, and with the threshold raised the kernel spilled 2 600 VGPRs.)
 #pragma unroll
           for (int j = 0; j < GS; j++) asm volatile("" : "+v"(bs[j]));
 #pragma unroll
