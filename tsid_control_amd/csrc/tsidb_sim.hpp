@@ -462,6 +462,8 @@ __device__ __forceinline__ int hull_argmin(const DevModel<T> &m, int lane, int b
   };
   unsigned long long scanned = 0;
   T zmin = INF;
+  T zk0 = INF, zk1 = INF; // this lane's values in the two chunks scanned last (the tie search below reads them again:
+  int ck0 = -1, ck1 = -1; //  a foot is decided in one or two chunks, and the reload is a global-memory round trip)
   {
     T zl = zlb;
     int ci = lane;
@@ -472,6 +474,7 @@ __device__ __forceinline__ int hull_argmin(const DevModel<T> &m, int lane, int b
       const int i = v0 + WAVE * c + lane;
       T z = INF;
       if (i < v1) z = vert_val(i);
+      zk1 = zk0; ck1 = ck0; zk0 = z; ck0 = c;
       const T zc2 = wave_min(z);
       zmin = zc2 < zmin ? zc2 : zmin;
       scanned |= 1ull << c;
@@ -485,8 +488,12 @@ __device__ __forceinline__ int hull_argmin(const DevModel<T> &m, int lane, int b
   for (unsigned long long sm = scanned; sm && best == 0x7fffffff; sm &= sm - 1) {
     const int c = __ffsll((long long)sm) - 1;
     const int i = v0 + WAVE * c + lane;
+    T zv;
+    if (c == ck0) zv = zk0;
+    else if (c == ck1) zv = zk1;
+    else zv = i < v1 ? vert_val(i) : INF;
     int cand = 0x7fffffff;
-    if (i < v1 && vert_val(i) <= zt) cand = i;
+    if (i < v1 && zv <= zt) cand = i;
     best = wave_min_int(cand);
   }
   // non-finite values (a NaN placement) match nothing: hand back a valid index, the callers index global memory with it
@@ -1144,6 +1151,12 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
       const T pzl = dot3(fl.n, L.p[gb]) + nO;
       const T zc = c6 * m.rbound[lane][0] + c7 * m.rbound[lane][1] + c8 * m.rbound[lane][2] + pzl;
       near = !(zc - m.rbound[lane][3] - hmax_all > margin);
+      // second, tighter bound: the hull's body-frame box (centre, half extents) projected on the floor normal.  A swinging
+      // foot a few centimetres up is inside its bounding sphere's reach of the floor but not its box's: no support search
+      // for it (a whole pruned hull search, 5 % of a step, for most of every swing).  Exact: a lower bound of every vertex.
+      const T *hb = m.hbox[lane];
+      const T zb = c6 * hb[0] + c7 * hb[1] + c8 * hb[2] + pzl - (fabs(c6) * hb[3] + fabs(c7) * hb[4] + fabs(c8) * hb[5]);
+      near = near && !(zb - fabs(zb) * T(8) * Eps<T>::v - hmax_all > margin);
     }
     cand_geoms = __ballot(near);
   }
