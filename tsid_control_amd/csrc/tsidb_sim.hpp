@@ -67,6 +67,8 @@ struct SimLds {
   unsigned anc[NB]; // ancestor bitmask per body (copied from the model: LDS latency, not global)
   T cr[MAXCON][3], cdist[MAXCON], cfv[MAXCON][3]; // contact point (rel O), distance, force vector
   int xch[4]; // two-wavefront variant: ncon, nfl, cross-branch flag, flag bits handed from the collision wavefront to the other
+  unsigned char cchain[MAXCON][8]; // floor contacts: the contact body and its non-root ancestors, deepest first, 0 padded
+                                   // (the chain table's row of the body, kept beside the contact: static chain walks)
 };
 static_assert(sizeof(SimLds<double>) <= 20480, "k_sim must fit 8 workgroups per CU");
 
@@ -335,6 +337,25 @@ __device__ __forceinline__ void contact_rows(const DevModel<T> &m, const SimLds<
   T n[3], t1[3], t2[3];
   const int b1 = contact_frame(L, c, nfl, n, t1, t2);
   T tw[6] = {0, 0, 0, 0, 0, 0};
+  if (b1 < 0) {
+    // floor contact: the root's six dofs, then the body's chain from the shallowest ancestor down (the bytes stored with the
+    // contact) - a static walk, every load independent; the same order of sums as the bit-mask loop below
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+      const T xk = x[k];
+#pragma unroll
+      for (int i = 0; i < 6; i++) tw[i] += L.S[k][i] * xk;
+    }
+#pragma unroll
+    for (int d = 6; d >= 0; d--) {
+      const int a = L.cchain[c][d];
+      if (a > 0) {
+        const T xk = x[5 + a];
+#pragma unroll
+        for (int i = 0; i < 6; i++) tw[i] += L.S[5 + a][i] * xk;
+      }
+    }
+  } else {
   const unsigned m2 = L.anc[L.cbody[c]], m1 = b1 >= 0 ? L.anc[b1] : 0u;
 #pragma unroll
   for (int side = 0; side < 2; side++) {
@@ -354,6 +375,7 @@ __device__ __forceinline__ void contact_rows(const DevModel<T> &m, const SimLds<
         for (int i = 0; i < 6; i++) tw[i] += L.S[5 + a][i] * xk;
       }
     }
+  }
   }
   T wxr[3];
   cross3(tw + 3, L.cr[c], wxr);
@@ -379,23 +401,34 @@ __device__ __forceinline__ void contact_rows_multi(const DevModel<T> &m, const S
   for (int k = 0; k < K; k++)
 #pragma unroll
     for (int i = 0; i < 6; i++) tw[k][i] = 0;
-  const unsigned m2 = L.anc[L.cbody[c]], m1 = b1 >= 0 ? L.anc[b1] : 0u;
+  auto add_dof = [&](int d, T sg) {
+    T Sd[6];
 #pragma unroll
-  for (int side = 0; side < 2; side++) {
-    const T sg = side == 0 ? T(1) : T(-1);
-    for (unsigned mk = side == 0 ? (m2 & ~m1) : (m1 & ~m2); mk; mk &= mk - 1) {
-      const int a = __ffs(mk) - 1;
-      const int d0 = a == 0 ? 0 : 5 + a, d1 = a == 0 ? 5 : 5 + a;
-      for (int d = d0; d <= d1; d++) {
-        T Sd[6];
+    for (int i = 0; i < 6; i++) Sd[i] = L.S[d][i];
 #pragma unroll
-        for (int i = 0; i < 6; i++) Sd[i] = L.S[d][i];
+    for (int k = 0; k < K; k++) {
+      const T xk = sg * x[k][d];
 #pragma unroll
-        for (int k = 0; k < K; k++) {
-          const T xk = sg * x[k][d];
+      for (int i = 0; i < 6; i++) tw[k][i] += Sd[i] * xk;
+    }
+  };
+  if (b1 < 0) { // floor contact: static walk over the chain stored with the contact (see contact_rows)
 #pragma unroll
-          for (int i = 0; i < 6; i++) tw[k][i] += Sd[i] * xk;
-        }
+    for (int d = 0; d < 6; d++) add_dof(d, T(1));
+#pragma unroll
+    for (int d = 6; d >= 0; d--) {
+      const int a = L.cchain[c][d];
+      if (a > 0) add_dof(5 + a, T(1));
+    }
+  } else {
+    const unsigned m2 = L.anc[L.cbody[c]], m1 = L.anc[b1];
+#pragma unroll
+    for (int side = 0; side < 2; side++) {
+      const T sg = side == 0 ? T(1) : T(-1);
+      for (unsigned mk = side == 0 ? (m2 & ~m1) : (m1 & ~m2); mk; mk &= mk - 1) {
+        const int a = __ffs(mk) - 1;
+        const int d0 = a == 0 ? 0 : 5 + a, d1 = a == 0 ? 5 : 5 + a;
+        for (int d = d0; d <= d1; d++) add_dof(d, sg);
       }
     }
   }
@@ -1237,6 +1270,8 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
       L.cdist[slot] = dist;
 #pragma unroll
       for (int i = 0; i < 3; i++) L.cr[slot][i] = cp[i];
+#pragma unroll
+      for (int d = 0; d < 7; d++) { const int a = m.mj_chain[b][d]; L.cchain[slot][d] = (unsigned char)(a > 0 ? a : 0); }
     }
     ncon += __popcll(mask);
     ncon = ncon > MAXCON ? MAXCON : ncon;
