@@ -1487,6 +1487,9 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
     // two branches of the tree (dense factor).  In a touch-down window 80 % of the later iterations change <= 2 rows
     // (tools/newton_stats.py).  Between iterations the factor is parked in the LDS copy of H (column 26: 1 / diagonal).
     bool have_fac = false;
+    // the floor contacts arrive grouped by body: bit c = contact c is the first of its body's group (fixed for the step)
+    const unsigned long long gfirst = __ballot(lane < nfl && (lane == 0 || L.cbody[lane] != L.cbody[lane > 0 ? lane - 1 : 0]));
+    const bool grouped = nfl > 2;
     unsigned prevbits = 0; // bit 0: this lane's friction row was in its quadratic zone, bit 1 + i: contact row i was active
     TSIDB_LAP_ZERO(24); TSIDB_LAP_ZERO(25); TSIDB_LAP_ZERO(26); TSIDB_LAP_ZERO(27); TSIDB_LAP_ZERO(28);
     TSIDB_LAP_INIT();
@@ -1536,14 +1539,45 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
           }
         }
         L.cfv[lane][0] = fv[0]; L.cfv[lane][1] = fv[1]; L.cfv[lane][2] = fv[2];
+        if (grouped && lane < nfl) { // floor contact: its wrench about O, for the per-body sums below (the composite-inertia scratch is free)
+          T rxf[3];
+          cross3(L.cr[lane], fv, rxf);
+          if constexpr (CONDIM > 3) { rxf[0] += L.ctq[lane][0]; rxf[1] += L.ctq[lane][1]; rxf[2] += L.ctq[lane][2]; }
+          T *gw = &L.K[0][0] + 6 * lane;
+          gw[0] = fv[0]; gw[1] = fv[1]; gw[2] = fv[2]; gw[3] = rxf[0]; gw[4] = rxf[1]; gw[5] = rxf[2];
+        }
       }
       wsync<NW>();
-      // ---- gradient: Ma - qfrc_smooth - J^T force
+      // ---- gradient: Ma - qfrc_smooth - J^T force.  With more than two floor contacts their wrenches are summed per contact
+      //      BODY first (lane e sums component e over each group, in place), then dof k takes S_k . (sum of the groups below
+      //      it) - a handful of groups instead of a loop over every contact per dof; robot<->robot contacts, and one or two
+      //      floor contacts, keep the per-contact form (the extra exchange costs more than it saves there)
+      if (grouped) {
+        for (unsigned long long gm = gfirst; gm; gm &= gm - 1) {
+          const int cf = __ffsll((long long)gm) - 1;
+          const unsigned long long rest = gm & (gm - 1);
+          const int ce = rest ? __ffsll((long long)rest) - 1 : nfl;
+          if (lane < 6) {
+            T acc = 0;
+            for (int c = cf; c < ce; c++) acc += (&L.K[0][0])[6 * c + lane];
+            (&L.K[0][0])[6 * cf + lane] = acc;
+          }
+        }
+        wsync<NW>();
+      }
       T grad = 0;
       if (lane < NV) {
         const int k = lane, bk = k < 6 ? 0 : k - 5;
         T s = 0;
-        for (int c = 0; c < ncon; c++) {
+        if (grouped)
+          for (unsigned long long gm = gfirst; gm; gm &= gm - 1) {
+            const int cf = __ffsll((long long)gm) - 1;
+            if ((L.anc[L.cbody[cf]] >> bk) & 1u) {
+              const T *gw = &L.K[0][0] + 6 * cf;
+              s += L.S[k][0] * gw[0] + L.S[k][1] * gw[1] + L.S[k][2] * gw[2] + L.S[k][3] * gw[3] + L.S[k][4] * gw[4] + L.S[k][5] * gw[5];
+            }
+          }
+        for (int c = grouped ? nfl : 0; c < ncon; c++) {
           // +1 on geom2's chain, -1 on geom1's, 0 above their common ancestor
           int sgn = (int)((L.anc[L.cbody[c]] >> bk) & 1u);
           if (c >= nfl) sgn -= (int)((L.anc[L.hb1[c - nfl]] >> bk) & 1u);
@@ -1632,10 +1666,7 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
       // plain loads and one store per entry (the first version pushed every group sum to every ancestor with dependent
       // LDS read-modify-writes, after zeroing K: 3-4 k cycles of latency per build; same sums in the same order)
       unsigned touched = 0;
-      unsigned long long gfirst; // bit c: floor contact c is the first of its body's group
       {
-        const bool isfirst = lane < nfl && (lane == 0 || L.cbody[lane] != L.cbody[lane > 0 ? lane - 1 : 0]);
-        gfirst = __ballot(isfirst);
         for (unsigned long long gm = gfirst; gm; gm &= gm - 1) {
           const int cf = __ffsll((long long)gm) - 1;
           const unsigned long long rest = gm & (gm - 1);
