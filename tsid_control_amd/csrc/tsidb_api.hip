@@ -627,6 +627,7 @@ static void chain_table(const int *parent, int n, int (*chain)[8]) {
 struct tsidb_ctx {
   int device = 0, dtype = 0, num_envs = 0;
   int sim_waves = 1; // wavefronts per env in k_sim (tsidb_set_option)
+  unsigned lds_pad = 0; // diagnostic: unused dynamic LDS per workgroup of k_tick / k_sim (occupancy experiments)
   Blob blob;
   std::vector<double> params;
   void *d_model = nullptr, *d_hull = nullptr, *d_box = nullptr;
@@ -901,7 +902,7 @@ static void launch_tick(tsidb_ctx *h, void *q, void *v, void *tau, void *dv, voi
   memset(&wa, 0, sizeof wa);
   if (walk) wa = *walk;
 #define TSIDB_LAUNCH_TICK(COP)                                                                                             \
-  hipLaunchKernelGGL((k_tick<T, COP>), dim3(h->num_envs), dim3(WAVE), 0, s, (const DevModel<T> *)h->d_model, h->num_envs,   \
+  hipLaunchKernelGGL((k_tick<T, COP>), dim3(h->num_envs), dim3(WAVE), h->lds_pad, s, (const DevModel<T> *)h->d_model, h->num_envs,   \
                      (T *)q, (T *)v, (const T *)h->com_ref, (const T *)h->posture_ref, (const T *)h->foot_ref,             \
                      (const T *)h->contact_ref, h->contact_active, (const T *)h->cop_frames, (T *)tau, (T *)dv, (T *)f,    \
                      status, (T *)obs, obs_ld, (T *)frames, info, (const T *)qpos_sim, (const T *)qvel_sim, (const T *)h->cop_ref, wa, \
@@ -929,7 +930,7 @@ static void launch_sim(tsidb_ctx *h, int B, const void *q_ring, const void *v_ri
     // unconstrained dynamics), bit-identical results.  Measured: 512 envs sim 0.083 -> 0.077 ms; at 1024 and 2048 envs the
     // extra wavefronts queue behind the others and nothing is gained
 #define TSIDB_LAUNCH_SIM(NW, MULTI)                                                                                                    \
-    hipLaunchKernelGGL((k_sim<T, NW, MULTI>), dim3(h->num_envs), dim3(WAVE * NW), 0, s, (const DevModel<T> *)h->d_model, h->num_envs, B, ring, \
+    hipLaunchKernelGGL((k_sim<T, NW, MULTI>), dim3(h->num_envs), dim3(WAVE * NW), h->lds_pad, s, (const DevModel<T> *)h->d_model, h->num_envs, B, ring, \
                        (T *)qpos, (T *)qvel, (T *)qacc_ws, (const T *)h->env_params, (const T *)h->terrain, (const T *)motor_tau,     \
                        (T *)qacc, ncon, con, info)
     if (B > 1) { if (h->sim_waves == 2) TSIDB_LAUNCH_SIM(2, true); else TSIDB_LAUNCH_SIM(1, true); }
@@ -1061,6 +1062,7 @@ int tsidb_set_refs(tsidb_handle h, const void *com_ref, const void *posture_ref,
 int tsidb_set_option(tsidb_handle h, int option, int value) {
   if (!h) return -1;
   if (option == TSIDB_OPT_SIM_WAVES && (value == 1 || value == 2)) { h->sim_waves = value; return 0; }
+  if (option == TSIDB_OPT_LDS_PAD && value >= 0 && value <= 40960) { h->lds_pad = (unsigned)value; return 0; }
   h->err = "tsidb_set_option: unknown option or value";
   return 1;
 }

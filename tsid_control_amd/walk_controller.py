@@ -89,6 +89,8 @@ class WalkController:
         sw = int(getattr(conf, "sim_waves", 0))   # 0 = the library's choice (2 wavefronts per env up to 384 envs, else 1)
         if sw:
             _lib.check(L, self._h, L.tsidb_set_option(self._h, 1, sw), "tsidb_set_option(sim_waves)")
+        if os.environ.get("TSIDB_LDS_PAD"):       # diagnostic (occupancy measurements): unused LDS per workgroup
+            _lib.check(L, self._h, L.tsidb_set_option(self._h, 2, int(os.environ["TSIDB_LDS_PAD"])), "tsidb_set_option(lds_pad)")
         self.cop_ref = z(N, 3)   # reference of the CoP force task (legacy/biped.py:79-80; conf.w_cop)
         _lib.check(L, self._h, L.tsidb_set_cop_ref(self._h, _ptr(self.cop_ref)), "tsidb_set_cop_ref")
 
