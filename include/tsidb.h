@@ -193,7 +193,8 @@ int tsidb_set_posture_bias(tsidb_handle h, const void *posture_bias);
  * by U(scale_lo, scale_hi) drawn from hash(seed, env, episode[e]) (bump_episode != 0 increments episode[e] first), rotated
  * into the robot's heading and started between its feet.  Outputs: steps [N,K+2,4] float64 = x, y, yaw, side of every
  * footstep (the two initial ones first); nsteps [N]; coef, side, rest, com as tsidb_walk_update reads them; flags [N] (may
- * be NULL) bit 0 = the plan needed more than K steps and was cut.  The env's clock restarts: t_offset [N] (may be NULL)
+ * be NULL) bit 0 = the plan needed more than K steps and was cut, bit 1 = the path had no direction (fewer than two distinct
+ * vertices; npts[e] is clamped to P): no step planned, the env stands.  The env's clock restarts: t_offset [N] (may be NULL)
  * receives `t` (or *t_device, float64 device), td_latch [N] (may be NULL) -1. */
 enum { TSIDB_PLAN_NPARAMS = 16 };
 int tsidb_walk_plan(tsidb_handle h, const int32_t *env_ids, int n_ids, const void *done_rows, int rows_ld,

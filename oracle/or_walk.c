@@ -149,7 +149,8 @@ void or_walk_update_fb(int n, const double *coef, const int32_t *side, const int
  *         vertices at most resample_ds apart, rotated into the robot's heading and started between its feet.
  * cop_frames [n,2,12] (R row-major, p): the sole placements the episode starts from; com_ref [n,9]: its CoM.
  * Outputs: steps [n,K+2,4] = x, y, yaw (world), side; nsteps [n]; coef [n,K,4,4]; side [n,K]; rest [n,K+1,2,4]; com
- * [n,K+2,2,3]; flags [n] bit 0 = the plan had more than K steps and was cut. */
+ * [n,K+2,2,3]; flags [n] bit 0 = the plan had more than K steps and was cut, bit 1 = the
+ * path had no direction (fewer than two distinct vertices): no step planned. */
 uint64_t or_plan_hash(uint64_t seed, uint64_t env, uint64_t episode) {
   uint64_t x = seed ^ (env * 0x9E3779B97F4A7C15ull) ^ (episode * 0xD1B54A32D192ED03ull);
   x += 0x9E3779B97F4A7C15ull;
@@ -206,7 +207,8 @@ void or_walk_plan(int n, const double *pp, const double *cop_frames, const doubl
       if (scale) sc = scale[e];
       else if (episode) sc = pp[13] + (pp[14] - pp[13]) * ((double)(or_plan_hash((uint64_t)pp[15], (uint64_t)e, (uint64_t)episode[e]) >> 11) * (1.0 / 9007199254740992.0));
     }
-    const int nv = path ? npts[e] : (int)pp[12];
+    int nv = path ? npts[e] : (int)pp[12];
+    if (path && nv > P) nv = P;
     double ux = 0, uy = 0, uth = 0;
     for (int i = 0; i < nv; i++) {
       double b[2];
@@ -222,8 +224,9 @@ void or_walk_plan(int n, const double *pp, const double *cop_frames, const doubl
       if (m < 1) m = 1;
       for (int j = 1; j <= m; j++) {
         const double q = (double)j / m, p[2] = {a[0] + (b[0] - a[0]) * q, a[1] + (b[1] - a[1]) * q};
-        dx = p[0] - prev[0]; dy = p[1] - prev[1];
-        travelled += hypot(dx, dy);
+        const double ddx = p[0] - prev[0], ddy = p[1] - prev[1];
+        if (ddx != 0 || ddy != 0) { dx = ddx; dy = ddy; } /* (a repeated vertex keeps the direction of the piece before it) */
+        travelled += hypot(ddx, ddy);
         if (travelled >= L) {
           sd = !sd;
           if (nst < K + 2) plan_add_step(pp, dx, dy, sd, prev, &st[nst++]); else cut = 1;
@@ -233,15 +236,20 @@ void or_walk_plan(int n, const double *pp, const double *cop_frames, const doubl
       }
       a[0] = b[0]; a[1] = b[1];
     }
-    sd = !sd; /* closing step at the end of the path, one more if the last stretch was partial (:114-123) */
-    if (nst < K + 2) plan_add_step(pp, dx, dy, sd, prev, &st[nst++]); else cut = 1;
-    if (travelled > 0) {
+    /* closing step at the end of the path, one more if the last stretch was partial (:114-123); a path without a direction
+     * (fewer than two distinct vertices: the reference raises) plans no step, flag bit 1 */
+    const int degenerate = !(dx != 0 || dy != 0);
+    if (!degenerate) {
       sd = !sd;
       if (nst < K + 2) plan_add_step(pp, dx, dy, sd, prev, &st[nst++]); else cut = 1;
+      if (travelled > 0) {
+        sd = !sd;
+        if (nst < K + 2) plan_add_step(pp, dx, dy, sd, prev, &st[nst++]); else cut = 1;
+      }
     }
     const int ns = nst - 2;
     nsteps[e] = ns;
-    if (flags) flags[e] = cut;
+    if (flags) flags[e] = cut | (degenerate ? 2 : 0);
     for (int k = 0; k < K + 2; k++) {
       double *o = steps_out + ((size_t)e * (K + 2) + k) * 4;
       if (k < nst) { o[0] = st[k].x; o[1] = st[k].y; o[2] = st[k].yaw; o[3] = st[k].side; }

@@ -1277,6 +1277,21 @@ def test_plan_kernel_matches_restatement_and_reference_footsteps(oracle, dtype):
         want = np.array([[s["pos"][0], s["pos"][1], s["yaw"], int(s["side"])] for s in c["steps"]])
         assert int(sched.nsteps[i]) + 2 == len(want)
         assert diff(sched.steps[i, :len(want)], want) < (1e-12 if dtype == "f64" else 1e-7)   # (f32: the feet positions are read as float32)
+    # paths without a direction plan no step and flag it (bit 1); npts beyond the row length is clamped - same as the twin
+    path[:] = 0.0
+    path[0, :4] = [[0, 0], [0, 0.3], [0, 0.6], [0, 0.9]]
+    path[1, :4] = [[0.1, 0.2]] * 4
+    npts[:] = 1
+    npts[0], npts[1] = P + 5, 4
+    path[0, 4:] = path[0, 3]                      # (the clamp reads the whole row: keep it a valid polyline)
+    sched.pp = plan_params(wc.conf, resample_ds=0.0)
+    sched.plan(wc, env_ids=[0, 1, 2], path=path, npts=npts)
+    twin = walk_plan(oracle.lib, sched.pp, wc.cop_frames.double().cpu().numpy()[:3], wc.com_ref.double().cpu().numpy()[:3], sched.K,
+                     path=path[:3], npts=np.minimum(npts[:3], P))
+    assert sched.flags[:3].cpu().tolist() == [0, 2, 2] == twin["flags"].tolist()
+    assert sched.nsteps[:3].cpu().tolist() == twin["nsteps"].tolist() and int(sched.nsteps[1]) == 0
+    for k in ("steps", "coef", "rest", "com"):
+        assert torch.isfinite(getattr(sched, k)[:3]).all() and diff(getattr(sched, k)[:3], twin[k]) < (tol if k != "steps" else 1e-7), k
 
 
 def test_episode_lifecycle_on_the_device():

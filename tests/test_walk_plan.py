@@ -90,3 +90,23 @@ def test_plan_path_scale_draws(oracle):
     oracle.lib.or_plan_hash.restype = __import__("ctypes").c_uint64
     oracle.lib.or_plan_hash.argtypes = [__import__("ctypes").c_uint64] * 3
     assert oracle.lib.or_plan_hash(11, 3, 0) != oracle.lib.or_plan_hash(11, 3, 1) != oracle.lib.or_plan_hash(11, 4, 1)
+
+
+def test_plan_degenerate_paths(oracle):
+    """a path without a direction (one vertex, or all vertices equal; the reference's planner raises there) plans no step
+    and says so in flag bit 1; npts beyond the table's row length is clamped to it"""
+    conf = op3_walking_conf(RobotConfig())
+    fr, cr = standing(3)
+    path = np.zeros((3, 4, 2))
+    path[0] = [[0, 0], [0, 0.3], [0, 0.6], [0, 0.9]]
+    path[1] = [[0.1, 0.2]] * 4                      # all vertices equal
+    path[2] = [[0, 0], [0, 0.3], [0, 0.6], [0, 0.9]]
+    out = walk_plan(oracle.lib, plan_params(conf), fr, cr, 40, path=path, npts=[4, 4, 1])
+    assert out["flags"].tolist() == [0, 2, 2] and out["nsteps"][0] > 10 and out["nsteps"][1] == 0 and out["nsteps"][2] == 0
+    assert np.isfinite(out["steps"]).all() and np.isfinite(out["coef"]).all() and np.isfinite(out["com"]).all()
+    assert not out["coef"][1:].any()                 # nobody swings
+    big = walk_plan(oracle.lib, plan_params(conf), fr[:1], cr[:1], 40, path=path[:1], npts=[9])   # 9 > P = 4: clamped
+    assert np.array_equal(big["steps"], out["steps"][:1]) and big["flags"][0] == 0
+    rep = np.concatenate([path[:1], np.repeat(path[:1, 3:], 3, axis=1)], axis=1)                  # the last vertex three more times
+    same = walk_plan(oracle.lib, plan_params(conf), fr[:1], cr[:1], 40, path=rep, npts=[7])
+    assert np.array_equal(same["steps"], out["steps"][:1]) and same["flags"][0] == 0

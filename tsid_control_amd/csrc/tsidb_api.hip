@@ -418,7 +418,8 @@ __global__ __launch_bounds__(64) void k_plan(int n, const int *env_ids, int n_id
     if (scale) sc = scale[e];
     else if (episode) sc = pp[13] + (pp[14] - pp[13]) * ((double)(plan_hash((unsigned long long)pp[15], (unsigned long long)e, (unsigned long long)episode[e]) >> 11) * (1.0 / 9007199254740992.0));
   }
-  const int nv = path ? npts[e] : (int)pp[12];
+  int nv = path ? npts[e] : (int)pp[12];
+  if (path && nv > P) nv = P; // (never read past the env's row of the path table)
   double ux = 0, uy = 0, uth = 0;
   for (int i = 0; i < nv; i++) {
     double b[2];
@@ -434,19 +435,25 @@ __global__ __launch_bounds__(64) void k_plan(int n, const int *env_ids, int n_id
     if (mres < 1) mres = 1;
     for (int j = 1; j <= mres; j++) {
       const double qf = (double)j / mres, p[2] = {a[0] + (b[0] - a[0]) * qf, a[1] + (b[1] - a[1]) * qf};
-      dx = p[0] - prev[0]; dy = p[1] - prev[1];
-      travelled += hypot(dx, dy);
+      const double ddx = p[0] - prev[0], ddy = p[1] - prev[1];
+      if (ddx != 0 || ddy != 0) { dx = ddx; dy = ddy; } // (a repeated vertex keeps the direction of the piece before it)
+      travelled += hypot(ddx, ddy);
       if (travelled >= L) { sd = !sd; add_step(dx, dy, sd, prev); travelled = 0; }
       prev[0] = p[0]; prev[1] = p[1];
     }
     a[0] = b[0]; a[1] = b[1];
   }
-  sd = !sd;
-  add_step(dx, dy, sd, prev);
-  if (travelled > 0) { sd = !sd; add_step(dx, dy, sd, prev); }
+  // a path without a direction (fewer than two distinct vertices; the reference's planner raises on it) plans no step: the env
+  // stands, flag bit 1
+  const bool degenerate = !(dx != 0 || dy != 0);
+  if (!degenerate) {
+    sd = !sd;
+    add_step(dx, dy, sd, prev);
+    if (travelled > 0) { sd = !sd; add_step(dx, dy, sd, prev); }
+  }
   const int ns = nst - 2;
   nsteps[e] = ns;
-  if (flags) flags[e] = cut;
+  if (flags) flags[e] = cut | (degenerate ? 2 : 0);
   for (int k = nst; k < K + 2; k++) st[4 * k] = st[4 * k + 1] = st[4 * k + 2] = st[4 * k + 3] = 0;
   // swing polynomials and rest placements; yaw relative to the initial heading
   double cur[2][4];
