@@ -93,8 +93,8 @@ class RobotConfig:
     mask_am = (1.0, 1.0, 0.0)  #   (legacy/biped.py:83), zero reference (legacy/biped.py:86-87)
     qp_max_iter = 1000         # eiquadprog-fast DEFAULT_MAX_ITER
     hessian_regularization = 1e-8  # tsid SolverHQuadProgFast default
-    pipeline_sim_batch = 0     # WalkController.step_pipelined(): sim stages enqueued on their stream this many at a time; 0 = auto
-                               # (4 for up to 1024 envs, else 1)
+    pipeline_sim_batch = 0     # WalkController.step_pipelined(): sim stages enqueued on their stream this many at a time, as ONE
+                               # launch that steps every env that many times (at most 8); 0 = auto (8 for up to 1024 envs, else 1)
     sim_waves = 0              # wavefronts per env in the sim kernel: 1, 2 (collision phase beside the unconstrained dynamics: lower
                                # step latency for small batches; bit-identical), 0 = auto (2 up to 384 envs)
     self_collision = True      # sim stage collides the robot<->robot convex-hull pairs, as mj_step does (main.py:195);

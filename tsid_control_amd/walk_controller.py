@@ -265,17 +265,18 @@ class WalkController:
 
     def step_pipelined(self, events=None, walk=None):
         """One env step with the sim stage left running on a second HIP stream, so that it overlaps with
-        what the caller enqueues next on the current stream - normally the reference update and the TSID
-        tick of the NEXT step.  The reference couples the two stages one way (the sim never feeds back into
-        TSID, main.py:119-129 vs :192-195), so sim(t) and tick(t+1) are independent; the TSID state is
-        handed to the sim through a two-slot snapshot.  tau, q, v, status, obs are valid on the current
-        stream as after step(); the sim state (qpos, qvel, qacc_warmstart, ncon, con_pairs, info[:, 2:4])
-        is valid after sync_sim() ONLY (walk = (schedule, t) runs that tick's WalkSchedule.apply inside the tick's launch): with conf.pipeline_sim_batch > 1 (the default for up to 1024 envs is 4) the
-        last few sim stages are not even launched until the batch is full, so a device / stream synchronize does
-        not make the sim state current - sync_sim() launches them and makes the current stream wait.  Every entry
-        point of this class that reads or rewrites sim-side data (step, sim_step, reset, set_params, set_env_params,
-        capture_steps, WalkSchedule.apply with touch-down feedback) calls it.  `events` = four torch.cuda.Event
-        recorded around the tick (current stream) and around the sim (sim stream), for timing."""
+        what the caller enqueues next on the current stream - normally the TSID tick of the NEXT step.  The reference
+        couples the two stages one way (the sim never feeds back into TSID, main.py:119-129 vs :192-195), so sim(t) and
+        tick(t+1) are independent; the TSID state is handed to the sim through a ring of snapshot slots the tick writes.
+        walk = (schedule, t) runs that tick's WalkSchedule.apply inside the tick's launch (tsidb_tick_walk).
+        tau, q, v, status, obs are valid on the current stream as after step(); the sim state (qpos, qvel,
+        qacc_warmstart, ncon, con_pairs, info[:, 2:4]) is valid after sync_sim() ONLY: with conf.pipeline_sim_batch > 1
+        (the default for up to 1024 envs is 8) the last few sim stages are not even launched until the batch is full, so a
+        device / stream synchronize does not make the sim state current - sync_sim() launches them and makes the current
+        stream wait.  Every entry point of this class that reads or rewrites sim-side data (step, sim_step, reset,
+        reset_done, set_params, set_env_params, capture_steps, WalkSchedule.apply with touch-down feedback) calls it.
+        `events` = four torch.cuda.Event recorded around the tick (current stream) and around the sim (sim stream), for
+        timing."""
         if getattr(self.conf, "closed_loop", False) or not getattr(self.conf, "sim_enabled", True):
             raise _lib.TsidbError("step_pipelined needs the open-loop sim stage (closed loop: the tick reads the sim state)")
         cur = torch.cuda.current_stream(self.device)
@@ -283,7 +284,9 @@ class WalkController:
             # ring of snapshot slots: the tick writes its slot itself, so it must wait for the sim that read the slot
             # K steps ago BEFORE it starts - with only two slots that wait held tick(t) back until sim(t - 2) was done
             # and cost 12 % at 4096 envs; four slots and the tick stream runs ahead as before
-            K = max(4, int(os.environ.get("TSIDB_RING_SLOTS", "0")) or 2 * self.sim_batch)
+            # (never fewer than two batches of slots: a tick must not overwrite a snapshot whose sim is still pending; the
+            #  library numbers slots 0 .. 15)
+            K = min(16, max(4, 2 * self.sim_batch, int(os.environ.get("TSIDB_RING_SLOTS", "0"))))
             qring = torch.empty(K, *self.q.shape, dtype=self.dtype, device=self.device)   # one allocation: a batch of sim
             vring = torch.empty(K, *self.v.shape, dtype=self.dtype, device=self.device)   # stages names its slots by number
             self._pipe = dict(stream=torch.cuda.Stream(device=self.device), par=0, done=[None] * K, pending=[], qring=qring, vring=vring,
@@ -301,11 +304,10 @@ class WalkController:
         if events:
             events[1].record(cur)
         P["pending"].append(par)
-        # conf.pipeline_sim_batch > 1 enqueues the sim stages that many at a time (one cross-stream wait and one record
-        # per batch instead of per step; the sim state then lags the tick by up to that many steps until sync_sim()).
-        # Measured (DESIGN.md section 5 "Streams"): 4096 walkers, 4 at a time: +5 % in a touch-down window, -1 % on the
-        # phase average, 2 at a time -4 % - no batching there; 512 / 1024 walkers: +7 % / +5 % with 4 at a time (the default
-        # for up to 1024 envs).
+        # conf.pipeline_sim_batch > 1 enqueues the sim stages that many at a time, as one launch (one cross-stream wait and one
+        # record per batch instead of per step, no launch gaps; the sim state then lags the tick by up to that many steps
+        # until sync_sim()).  Measured (DESIGN.md section 5 "Streams"): no gain from 2048 envs on; 512 / 1024 walkers +25-30 %
+        # together with the fused tick launch (8 at a time, the default for up to 1024 envs).
         if len(P["pending"]) >= self.sim_batch or events:
             self._flush_sims(events)
         self.t += self.conf.dt

@@ -211,6 +211,8 @@ class WalkSchedule:
         self.steps, self.flags = z(N, K + 2, 4, dt=torch.float64), z(N, dt=torch.int32)
         self.episode = z(N, dt=torch.int32)
         self.scale = None if scale is None else torch.as_tensor(scale, dtype=torch.float64, device=dev).contiguous()
+        if self.scale is not None and self.scale.numel() != N:
+            raise ValueError("WalkSchedule.on_device: scale must hold one value per env")
         self.t_offset = z(N)
         self.td_latch, self.td_fraction = None, 0.6
         self._side32, self._nsteps32, self._coef_c, self._rest_c, self._com_c = self.side, self.nsteps, self.coef, self.rest, self.com
@@ -242,6 +244,9 @@ class WalkSchedule:
         if path is not None:
             path = torch.as_tensor(path, dtype=torch.float64, device=self.device).contiguous()
             npts = torch.as_tensor(npts, dtype=torch.int32, device=self.device).contiguous()
+            if path.dim() != 3 or path.shape[0] != self.N or path.shape[2] != 2 or path.shape[1] < 2 or npts.numel() != self.N:
+                raise _lib.TsidbError("WalkSchedule.plan: path must be [N, P >= 2, 2] and npts [N] (rows are indexed by env id, "
+                                      "also when only some envs are replanned)")
             self._path_keep = (path, npts)
         use_rng = path is None and self.scale is None
         with torch.cuda.device(wc.device):
