@@ -141,8 +141,11 @@ __device__ __forceinline__ void walk_update_env(const WalkArgs<T> &wa, int e, in
 // the previous step): 11.0 M -> 12.9 M env-steps/s from merging them.
 // COP: the variant with the CoP force task rows (legacy/biped.py:79-80) compiled in; the reference's
 // ctrl/WalkController.py stack (w_cop = 0) runs the variant without them.
+#ifndef TSIDB_WPE
+#define TSIDB_WPE 2 // wavefronts per SIMD the float64 kernels are register-allocated for (LDS allows 2: DESIGN.md section 5)
+#endif
 template <typename T, bool COP>
-__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2))) void k_tick(const DevModel<T> *__restrict__ mp, int n, T *q, T *v, const T *com_ref,
+__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(TSIDB_WPE))) void k_tick(const DevModel<T> *__restrict__ mp, int n, T *q, T *v, const T *com_ref,
                                                   const T *posture_ref, const T *foot_ref, const T *contact_ref,
                                                   const uint8_t *cact, const T *cop_frames, T *tau, T *dv, T *f,
                                                   int *status, T *obs, int obs_ld, T *frames, int *info, const T *qpos_sim,
@@ -218,7 +221,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2))) void 
 //  bits each - sixteen separate pointers were 32 SGPRs live across the whole step body)
 template <typename T> struct SimRing { const T *q, *v; unsigned long long slots; };
 template <typename T, int NW, bool MULTI>
-__global__ __launch_bounds__(WAVE * NW) __attribute__((amdgpu_waves_per_eu(2))) void k_sim(const DevModel<T> *__restrict__ mp, int n, int B, SimRing<T> ring, T *qpos, T *qvel,
+__global__ __launch_bounds__(WAVE * NW) __attribute__((amdgpu_waves_per_eu(TSIDB_WPE))) void k_sim(const DevModel<T> *__restrict__ mp, int n, int B, SimRing<T> ring, T *qpos, T *qvel,
                                               T *qacc_ws, const T *env_params, const T *terrain, const T *motor_tau, T *qacc, int *ncon,
                                               int *con, int *info) {
   __shared__ SimLds<T> L;
