@@ -363,7 +363,27 @@ template <typename T> __device__ __forceinline__ void cross_mf(const T *v, const
 //   V, A       : sums over the node's root path (chain table: the node and its non-root ancestors) of S qd and of
 //                V x (S qd), which only add in this representation
 // bufA / bufB: two n*12 scratch areas, sq / cb: n rows of >= 6 (strides given), all in LDS.
-template <typename T>
+// LDS hand-over between the lanes of a ONE-wavefront workgroup.  A wavefront's LDS instructions execute in order, so nothing
+// has to be waited for - only the compiler has to keep the order; __syncthreads() additionally drains every outstanding LDS
+// AND global access (s_waitcnt vmcnt(0) lgkmcnt(0)) at each of the ~60 hand-overs of a step.  Measured (round 3,
+// -DTSIDB_WAVE_SYNC, tools/r03_ab.sh): no difference - 16.5 M env-steps/s at 4096 envs and 6.6 M at 512 either way, nothing is
+// in flight at those points that the next phase does not need - so the default stays the plain barrier.
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+#ifdef TSIDB_WAVE_SYNC
+#define TSIDB_SYNC1() wave_sync()
+#else
+#define TSIDB_SYNC1() __syncthreads()
+#endif
+template <int NW> __device__ __forceinline__ void wg_sync() { // every wavefront of the workgroup
+  if constexpr (NW == 1) TSIDB_SYNC1();
+  else __syncthreads();
+}
+
+template <typename T, int NW = 1>
 __device__ __forceinline__ void tree_forward(int lane, int n, int up0, int up1, int up2, const int (&chn)[7], T *bufA, T *bufB,
                                              T *sq, int sq_stride, T *cb, int cb_stride, T (&R)[9], T (&p)[3], T qd,
                                              T (&S)[6], T (&V)[6], T (&A)[6]) {
@@ -374,7 +394,7 @@ __device__ __forceinline__ void tree_forward(int lane, int n, int up0, int up1, 
 #pragma unroll
     for (int i = 0; i < 3; i++) bufA[lane * 12 + 9 + i] = p[i];
   }
-  __syncthreads();
+  wg_sync<NW>();
 #pragma unroll
   for (int r = 0; r < 3; r++) {
     const int u = r == 0 ? up0 : (r == 1 ? up1 : up2);
@@ -400,7 +420,7 @@ __device__ __forceinline__ void tree_forward(int lane, int n, int up0, int up1, 
 #pragma unroll
         for (int i = 0; i < 3; i++) dst[lane * 12 + 9 + i] = p[i];
       }
-      __syncthreads();
+      wg_sync<NW>();
     }
   }
   // joint motion vector (revolute about the node's z axis through p) and its rate; the root hands in V, A
@@ -419,7 +439,7 @@ __device__ __forceinline__ void tree_forward(int lane, int n, int up0, int up1, 
 #pragma unroll
     for (int i = 0; i < 6; i++) sq[lane * sq_stride + i] = Sq[i];
   }
-  __syncthreads();
+  wg_sync<NW>();
   if (on && lane > 0) {
 #pragma unroll
     for (int i = 0; i < 6; i++) V[i] = sq[i]; // the root, then the node's chain from the shallowest ancestor down to itself:
@@ -444,7 +464,7 @@ __device__ __forceinline__ void tree_forward(int lane, int n, int up0, int up1, 
 #pragma unroll
     for (int i = 0; i < 6; i++) cb[lane * cb_stride + i] = cj[i];
   }
-  __syncthreads();
+  wg_sync<NW>();
   if (on && lane > 0) {
 #pragma unroll
     for (int i = 0; i < 6; i++) A[i] = cb[i];
@@ -457,7 +477,7 @@ __device__ __forceinline__ void tree_forward(int lane, int n, int up0, int up1, 
       }
     }
   }
-  __syncthreads(); // sq / cb / bufA / bufB are free again
+  wg_sync<NW>(); // sq / cb / bufA / bufB are free again
 }
 
 // log6 of a relative placement (R row-major, p) -> [v; w]   (pinocchio::log6 semantics)

@@ -76,7 +76,7 @@ static_assert(sizeof(SimLds<double>) <= 20480, "k_sim must fit 8 workgroups per 
 // is; in the two-wavefront variant the phases that run on different wavefronts at the same time must not meet at a
 // workgroup barrier, and need none: a wavefront's LDS instructions execute in order, only the compiler has to be told.
 template <int NW> __device__ __forceinline__ void wsync() {
-  if constexpr (NW == 1) __syncthreads();
+  if constexpr (NW == 1) TSIDB_SYNC1();
   else {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -998,7 +998,7 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
   }
   const T myctrl = (lane < NA && q_tsid) ? q_tsid[m.mj_ctrl_qidx[lane]] : T(0); // joint target of actuator `lane`
   for (int i = lane; i < NV * LDM; i += WAVE) L.M[i] = 0;
-  __syncthreads();
+  wg_sync<NW>();
   const T Oz = L.qpos[2];
 
   // ---- kinematics, velocities, bias accelerations: parent-independent work up front, the depth
@@ -1053,7 +1053,7 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
   int bchn[7];
 #pragma unroll
   for (int d = 0; d < 7; d++) bchn[d] = lane < NB ? m.mj_chain[lane][d] : -1;
-  tree_forward<T>(lane, NB, up0, up1, up2, bchn, &L.R[0][0], &L.V[0][0], &L.f[0][0], 6, &L.Yc[0][0], 10, Rb, pb, qd, Sb,
+  tree_forward<T, NW>(lane, NB, up0, up1, up2, bchn, &L.R[0][0], &L.V[0][0], &L.f[0][0], 6, &L.Yc[0][0], 10, Rb, pb, qd, Sb,
                   Vb, Ab);
   if (lane < NB) {
     const int b = lane;
@@ -1110,7 +1110,7 @@ __device__ __forceinline__ void sim_step_env(const DevModel<T> &m, SimLds<T> &L,
       for (int i = 0; i < 10; i++) L.Yc[lane][i] = Y[i];
     }
   }
-  __syncthreads();
+  wg_sync<NW>();
   const bool w_dyn = NW == 1 || wv == 0, w_col = NW == 1 || wv == NW - 1; // which phases this wavefront runs
   // ---- per dof: bias, mass-matrix column (+ armature), actuation
   T qfs = 0;

@@ -195,7 +195,7 @@ __device__ __forceinline__ void rbd_terms(const DevModel<T> &m, TickLds<T> &L, i
       for (int i = 0; i < 10; i++) K.Yc[lane][i] = Y[i];
     }
   }
-  __syncthreads();
+  TSIDB_SYNC1();
   TSIDB_LAP(30);
   // ---- per dof: bias, F = Yc S, mass-matrix entries, CoM Jacobian column
   const T invm = T(1) / m.mass;
@@ -275,7 +275,7 @@ __device__ __forceinline__ void rbd_terms(const DevModel<T> &m, TickLds<T> &L, i
     L.dLam[1] = f0[4] - (cz * f0[0] - cx * f0[2]);
     L.dLam[2] = f0[5] - (cx * f0[1] - cy * f0[0]);
   }
-  __syncthreads();
+  TSIDB_SYNC1();
   // ---- frame Jacobian columns (LOCAL) and CoM velocity
   if (lane < NV) {
     const int k = lane, jk = k < 6 ? 0 : k - 5;
@@ -311,7 +311,7 @@ __device__ __forceinline__ void rbd_terms(const DevModel<T> &m, TickLds<T> &L, i
       }
     }
   }
-  __syncthreads();
+  TSIDB_SYNC1();
 }
 
 // --------------------------------------------------------------------------- task right-hand sides
@@ -494,7 +494,7 @@ __device__ __forceinline__ int qp_active_regs(const DevModel<T> &m, TickLds<T> &
   T ul = 0; // lane k < na: multiplier of the k-th active inequality; lane na: the candidate's
   T R_norm = c.R_norm;
   for (int r = lane; r < c.nin; r += WAVE) S.cstate[r] = 0;
-  __syncthreads();
+  TSIDB_SYNC1();
 
   int iter = 0, status = -1;
   TSIDB_LAP_ZERO(10); TSIDB_LAP_ZERO(11); TSIDB_LAP_ZERO(12); TSIDB_LAP_ZERO(13); TSIDB_LAP_ZERO(14);
@@ -503,11 +503,11 @@ __device__ __forceinline__ int qp_active_regs(const DevModel<T> &m, TickLds<T> &
     // ---------------- l1: new outer iteration
     iter++;
     if (iter >= max_iter) { status = 3; break; }
-    __syncthreads();
+    TSIDB_SYNC1();
     if (lane < n) L.x[lane] = xl;
-    __syncthreads();
+    TSIDB_SYNC1();
     act_partials(L, n, lane);
-    __syncthreads();
+    TSIDB_SYNC1();
     T psi = 0;
 #pragma unroll
     for (int rr = 0; rr < 3; rr++) {
@@ -523,7 +523,7 @@ __device__ __forceinline__ int qp_active_regs(const DevModel<T> &m, TickLds<T> &
     if (fabs(psi) <= T(c.nin) * T(2.220446049250313e-16) * c1 * c2 * T(100)) { status = 0; break; }
     const T xold = xl, uold = ul;
     if (lane < na) S.Aold[lane] = S.A[lane];
-    __syncthreads();
+    TSIDB_SYNC1();
     TSIDB_LAP(10);
 
     bool outer_done = false;
@@ -649,14 +649,14 @@ __device__ __forceinline__ int qp_active_regs(const DevModel<T> &m, TickLds<T> &
             if (na >= NAS - 2 || ad <= Eps<T>::v * R_norm) {
               // numerically dependent on the active set: exclude it for this outer iteration and
               // fall back to the state saved at l1 (eiquadprog's recovery path)
-              __syncthreads();
+              TSIDB_SYNC1();
               if (lane == 0) S.cstate[ip] |= 2;
               for (int r = lane; r < c.nin; r += WAVE) S.cstate[r] &= 2;
-              __syncthreads();
+              TSIDB_SYNC1();
               if (lane < na) { S.A[lane] = S.Aold[lane]; S.cstate[S.Aold[lane]] |= 1; }
               ul = lane < na ? uold : T(0);
               xl = xold;
-              __syncthreads();
+              TSIDB_SYNC1();
               break; // back to l2
             }
             if (ad > R_norm) R_norm = ad;
@@ -664,7 +664,7 @@ __device__ __forceinline__ int qp_active_regs(const DevModel<T> &m, TickLds<T> &
             if (lane == 0) { S.Ra[rcol(na) + na] = dnew; S.Rinv[na] = T(1) / dnew; S.slot[na] = cstar; S.cstate[ip] |= 1; }
             freem &= ~(1ull << cstar);
             na++;
-            __syncthreads();
+            TSIDB_SYNC1();
             TSIDB_LAP(14);
             outer_done = true;
             break; // back to l1
@@ -673,7 +673,7 @@ __device__ __forceinline__ int qp_active_regs(const DevModel<T> &m, TickLds<T> &
         }
         if (drop) {
           // ---------------- remove active constraint l, then recompute the direction for ip
-          __syncthreads();
+          TSIDB_SYNC1();
           if (lane == 0) S.cstate[l] &= ~1;
           const int qq = wave_min_int((lane < na && S.A[lane] == l) ? lane : 9999);
           for (int j = qq; j < na - 1; j++) { // Givens sweep restoring the triangular factor
@@ -685,7 +685,7 @@ __device__ __forceinline__ int qp_active_regs(const DevModel<T> &m, TickLds<T> &
             T diag = h;
             if (cc < 0) { cc = -cc; ss = -ss; diag = -h; }
             const T xny = ss / (T(1) + cc);
-            __syncthreads();
+            TSIDB_SYNC1();
             for (int k = co + 1 + lane; k < na; k += WAVE) {
               const T a1 = S.Ra[rcol(k) + j], a2 = S.Ra[rcol(k) + j + 1];
               const T n1 = a1 * cc + a2 * ss;
@@ -698,19 +698,19 @@ __device__ __forceinline__ int qp_active_regs(const DevModel<T> &m, TickLds<T> &
             const T n1 = ta * cc + tb * ss, n2 = xny * (n1 + ta) - tb;
 #pragma unroll
             for (int jj = PP; jj < NN; jj++) jr[jj] = (jj == sa) ? n1 : ((jj == sb) ? n2 : jr[jj]);
-            __syncthreads();
+            TSIDB_SYNC1();
           }
           for (int k = qq + 1; k < na; k++) { // shift the packed columns left
             const T val = lane < k ? S.Ra[rcol(k) + lane] : T(0);
-            __syncthreads();
+            TSIDB_SYNC1();
             if (lane < k) S.Ra[rcol(k - 1) + lane] = val;
-            __syncthreads();
+            TSIDB_SYNC1();
           }
           if (lane >= qq && lane < na - 1) S.Rinv[lane] = T(1) / S.Ra[rcol(lane) + lane];
           int Av = 0;
           if (lane >= qq && lane < na) Av = S.A[lane + 1];
           const T unext = __shfl_down(ul, 1, WAVE);
-          __syncthreads();
+          TSIDB_SYNC1();
           if (lane >= qq && lane < na) S.A[lane] = Av;
           if (lane >= qq && lane <= na) ul = unext;
           const int freed = S.slot[na - 1];
@@ -718,21 +718,21 @@ __device__ __forceinline__ int qp_active_regs(const DevModel<T> &m, TickLds<T> &
           na--;
           if (lane == na + 1) ul = 0;
           // refresh s[ip] at the new point
-          __syncthreads();
+          TSIDB_SYNC1();
           if (lane < n) L.x[lane] = xl;
-          __syncthreads();
-          if (okind == 2) { act_partials(L, n, lane); __syncthreads(); }
+          TSIDB_SYNC1();
+          if (okind == 2) { act_partials(L, n, lane); TSIDB_SYNC1(); }
 #pragma unroll
           for (int rr = 0; rr < 3; rr++)
             if (rr == oround && lane == owner) S.s[ip] = row_eval(rd[rr], L);
-          __syncthreads();
+          TSIDB_SYNC1();
         }
       }
     }
   }
-  __syncthreads();
+  TSIDB_SYNC1();
   if (lane < n) L.x[lane] = xl;
-  __syncthreads();
+  TSIDB_SYNC1();
   c.iq = p + na;
   iter_out = iter;
   return status;
@@ -844,14 +844,14 @@ __device__ __forceinline__ void tick_qp(const DevModel<T> &m, TickLds<T> &L, QpC
       // six lanes doing it alone read the 78 constants of Jf0 as wave-uniform scalars: 156 SGPRs at once)
       static_assert(6 * 12 * NS <= 160, "force rows are staged in the active-set row buffer");
       T *fcl = L.as.s;
-      __syncthreads();
+      TSIDB_SYNC1();
       for (int idx = lane; idx < 6 * 12 * NS; idx += WAVE) {
         const int cl = idx / (12 * NS), rem = idx % (12 * NS), s2 = rem / 12, e = rem % 12;
         T sacc = 0;
         for (int b = 0; b <= e; b++) sacc += m.Jf0[b][e] * L.Dyn[cl * LDD + NV + 12 * s2 + b];
         fcl[idx] = sacc;
       }
-      __syncthreads();
+      TSIDB_SYNC1();
       if constexpr (COP) {
         const T w_cop = m.params[P_W_COP];
         if (w_cop != 0 && cop_ref) {
@@ -876,9 +876,9 @@ __device__ __forceinline__ void tick_qp(const DevModel<T> &m, TickLds<T> &L, QpC
             A0 = R[j] * x1[0] + R[3 + j] * x1[1] + R[6 + j] * x1[2]; // component j of R^T (t x d)
             A1 = R[j] * x2[0] + R[3 + j] * x2[1] + R[6 + j] * x2[2];
           }
-          __syncthreads();
+          TSIDB_SYNC1();
           if (isf) { L.x[fcol] = A0; L.x[24 + fcol] = A1; }
-          __syncthreads();
+          TSIDB_SYNC1();
           T t0 = 0, t1 = 0; // this lane's column of A J0 (J0 upper triangular within each foot's block)
           if (isf) {
             const int sl = fcol / 12, cb = fcol % 12;
@@ -893,9 +893,9 @@ __device__ __forceinline__ void tick_qp(const DevModel<T> &m, TickLds<T> &L, QpC
           const T bq = t1 - be1 * a12 * t0;
           const T al2 = wave_sum(bq * bq);
           const T be2 = al2 > tiny ? (1 - T(1) / sqrt(1 + w_cop * al2)) / al2 : T(0);
-          __syncthreads();
+          TSIDB_SYNC1();
           if (isf) { L.x[fcol] = t0; L.x[24 + fcol] = bq; }
-          __syncthreads();
+          TSIDB_SYNC1();
           if (isf) { // row of J: j0 (I - b1 a1 a1^T)(I - b2 b b^T)
             T s1 = 0, s2 = 0;
 #pragma unroll
@@ -924,7 +924,7 @@ __device__ __forceinline__ void tick_qp(const DevModel<T> &m, TickLds<T> &L, QpC
             for (int cc = 0; cc < 12 * NS; cc++) fcl[lane * 12 * NS + cc] = fc[cc];
           }
           c1 += w_cop * wave_sum(A0 * A0 + A1 * A1); // trace of the Hessian (tolerance scale only)
-          __syncthreads();
+          TSIDB_SYNC1();
         }
       }
       // rows of the force block go to their group's lane
@@ -935,7 +935,7 @@ __device__ __forceinline__ void tick_qp(const DevModel<T> &m, TickLds<T> &L, QpC
           if (row >= NV && row < NN) bs[j] = fcl[col * 12 * NS + row - NV];
         }
       }
-      __syncthreads(); // (the sweep below writes the row buffer)
+      TSIDB_SYNC1(); // (the sweep below writes the row buffer)
     }
     TSIDB_STAMP(5);
     // ---- Householder QR of B (column c on lanes c + PP g) applied to J (rows in lanes 0..n-1)
@@ -1044,7 +1044,7 @@ __device__ __forceinline__ void tick_qp(const DevModel<T> &m, TickLds<T> &L, QpC
     // ---- first feasibility sweep straight from registers' result; J / R go to LDS only if the
     //      active-set iterations are actually needed
     if (lane < n) L.x[lane] = xeq;
-    __syncthreads();
+    TSIDB_SYNC1();
     c.iq = p;
     c.R_norm = R_norm;
     int iters = 1;
@@ -1056,7 +1056,7 @@ __device__ __forceinline__ void tick_qp(const DevModel<T> &m, TickLds<T> &L, QpC
     for (int rr = 0; rr < 3; rr++) rdesc[rr] = row_desc(m, L, c, lane + WAVE * rr);
     if (status < 0) {
       act_partials(L, n, lane);
-      __syncthreads();
+      TSIDB_SYNC1();
       T psi = 0;
 #pragma unroll
       for (int rr = 0; rr < 3; rr++)
@@ -1107,11 +1107,11 @@ __device__ __forceinline__ void tsid_tick_env(const DevModel<T> &m, TickLds<T> &
     if (lane < NV) L.vs[lane] = v[lane];
   }
   if (lane >= 32 && lane < 34) L.act[lane - 32] = cact[lane - 32] != 0; // (the caller dispatched on act[0] + act[1] == NS)
-  __syncthreads();
+  TSIDB_SYNC1();
   rbd_terms(m, L, lane);
   if (m.params[P_TSID_ARMATURE] != 0) { // closed-loop knob: rotor inertia of the actuated joints in TSID's model
     if (lane >= 6 && lane < NV) L.Dyn[lane * LDD + lane] += m.params[P_TSID_ARMATURE];
-    __syncthreads();
+    TSIDB_SYNC1();
   }
   TSIDB_STAMP(1);
 
@@ -1146,7 +1146,7 @@ __device__ __forceinline__ void tsid_tick_env(const DevModel<T> &m, TickLds<T> &
     for (int i = 0; i < 6; i++) a += m.Tgen[i][e] * L.k.Jf[(6 * f + i) * LDF + r];
     L.Dyn[r * LDD + NV + cc] = -a;
   }
-  __syncthreads(); // kinematics scratch is dead from here on
+  TSIDB_SYNC1(); // kinematics scratch is dead from here on
   TSIDB_STAMP(2);
 
   // ---- Hessian block of dv in registers: lane i owns row i
@@ -1289,7 +1289,7 @@ __device__ __forceinline__ void tsid_tick_env(const DevModel<T> &m, TickLds<T> &
     status_out[0] = status;
     if (info) { info[0] = iters; info[1] = c.iq; }
   }
-  __syncthreads();
+  TSIDB_SYNC1();
   // ---- observations from this tick's data (main.py:132-142 reads data() before recomputing)
   if (obs) {
     // contact wrenches in the sole frames: component i of foot fo on lane 6 fo + i (twelve 12-term sums side by side
@@ -1332,7 +1332,7 @@ __device__ __forceinline__ void tsid_tick_env(const DevModel<T> &m, TickLds<T> &
       L.vs[lane] = vv + dt * dd;
       L.as.Ra[lane] = vm;
     }
-    __syncthreads();
+    TSIDB_SYNC1();
     if (lane >= 6 && lane < NV) L.qs[lane + 1] += vm;
     if (lane == 0) {
       const T *vl = &L.as.Ra[0], *w = &L.as.Ra[3];
@@ -1365,7 +1365,7 @@ __device__ __forceinline__ void tsid_tick_env(const DevModel<T> &m, TickLds<T> &
 #pragma unroll
       for (int i = 0; i < 4; i++) L.qs[3 + i] = r[i] * nn;
     }
-    __syncthreads();
+    TSIDB_SYNC1();
     if (lane < NQ) q[lane] = L.qs[lane];
     if (lane < NV) v[lane] = L.vs[lane];
   }
