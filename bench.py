@@ -288,7 +288,8 @@ def run_workload(a, dev, rank, world, n, with_gather=True):
         if a.steps % graph_steps:
             raise SystemExit("--steps must be a multiple of --graph")
         wc.t = (pre + a.warmup) * conf.dt
-        graph = wc.capture_steps(graph_steps, sched)
+        gsb = os.environ.get("TSIDB_GRAPH_SIM_BATCH")
+        graph = wc.capture_steps(graph_steps, sched, sim_batch=int(gsb) if gsb else None)
         graph.replay()                     # first launch uploads the graph: outside the timed region
         torch.cuda.synchronize()
         t0 = time.perf_counter()

@@ -125,8 +125,10 @@ int tsidb_sim(tsidb_handle h, const void *q_tsid, const void *v_tsid, void *qpos
 
 /* n_steps (1 .. TSIDB_MAX_SIM_BATCH) consecutive sim steps in ONE launch: step b teleports to / takes its joint targets from
  * slot slots[b] (host array, 0 .. 15) of the snapshot rings q_ring [K,N,27], v_ring [K,N,26] (v_ring may be NULL) - what n_steps
- * calls of tsidb_sim with q_tsid = q_ring[slots[b]] do, bit for bit, without the launch gaps between them (the pipelined
- * open-loop step hands over the TSID states of several ticks at once; envs do not interact, so each steps on its own).
+ * calls of tsidb_sim with q_tsid = q_ring[slots[b]] do, without the launch gaps between them (the pipelined open-loop step
+ * hands over the TSID states of several ticks at once; envs do not interact, so each steps on its own).  float64: bit for bit
+ * (tested over 1400 walking steps); float32: to rounding - the single- and the multi-step kernel are separate compilations of
+ * one source and fuse one multiply-add differently (first 1-ulp difference after 231 walking steps, tools/dbg_batch_f32.py).
  * ncon / con_pairs / info are the last step's. */
 enum { TSIDB_MAX_SIM_BATCH = 8 };
 int tsidb_sim_batch(tsidb_handle h, int n_steps, const void *q_ring, const void *v_ring, const int32_t *slots, void *qpos, void *qvel,

@@ -280,17 +280,7 @@ class WalkController:
         if getattr(self.conf, "closed_loop", False) or not getattr(self.conf, "sim_enabled", True):
             raise _lib.TsidbError("step_pipelined needs the open-loop sim stage (closed loop: the tick reads the sim state)")
         cur = torch.cuda.current_stream(self.device)
-        if getattr(self, "_pipe", None) is None:
-            # ring of snapshot slots: the tick writes its slot itself, so it must wait for the sim that read the slot
-            # K steps ago BEFORE it starts - with only two slots that wait held tick(t) back until sim(t - 2) was done
-            # and cost 12 % at 4096 envs; four slots and the tick stream runs ahead as before
-            # (never fewer than two batches of slots: a tick must not overwrite a snapshot whose sim is still pending; the
-            #  library numbers slots 0 .. 15)
-            K = min(16, max(4, 2 * self.sim_batch, int(os.environ.get("TSIDB_RING_SLOTS", "0"))))
-            qring = torch.empty(K, *self.q.shape, dtype=self.dtype, device=self.device)   # one allocation: a batch of sim
-            vring = torch.empty(K, *self.v.shape, dtype=self.dtype, device=self.device)   # stages names its slots by number
-            self._pipe = dict(stream=torch.cuda.Stream(device=self.device), par=0, done=[None] * K, pending=[], qring=qring, vring=vring,
-                              q=[qring[k] for k in range(K)], v=[vring[k] for k in range(K)])
+        self._ensure_pipe()
         P = self._pipe
         par = P["par"]
         P["par"] = (par + 1) % len(P["q"])
@@ -313,6 +303,26 @@ class WalkController:
         self.t += self.conf.dt
         return self.tau, self.q, self.v, self.status, self.obs
 
+    def _ensure_pipe(self):
+        """the second stream and the ring of snapshot slots step_pipelined() hands the TSID state to the sim stages through;
+        (re)built when missing or too small for the current sim batch"""
+        need = min(16, max(4, 2 * self.sim_batch, int(os.environ.get("TSIDB_RING_SLOTS", "0"))))
+        P = getattr(self, "_pipe", None)
+        if P is not None and len(P["q"]) >= need:
+            return
+        if P is not None:
+            self.sync_sim()                     # nothing may be pending in the ring that is replaced
+        # ring of snapshot slots: the tick writes its slot itself, so it must wait for the sim that read the slot
+        # K steps ago BEFORE it starts - with only two slots that wait held tick(t) back until sim(t - 2) was done
+        # and cost 12 % at 4096 envs; four slots and the tick stream runs ahead as before
+        # (never fewer than two batches of slots: a tick must not overwrite a snapshot whose sim is still pending; the
+        #  library numbers slots 0 .. 15)
+        K = need
+        qring = torch.empty(K, *self.q.shape, dtype=self.dtype, device=self.device)   # one allocation: a batch of sim
+        vring = torch.empty(K, *self.v.shape, dtype=self.dtype, device=self.device)   # stages names its slots by number
+        self._pipe = dict(stream=torch.cuda.Stream(device=self.device), par=0, done=[None] * K, pending=[], qring=qring, vring=vring,
+                          q=[qring[k] for k in range(K)], v=[vring[k] for k in range(K)])
+
     def gather_rows(self, out=None):
         """[N, 67] = obs, reward, done of the last tick: the per-env row the multi-GPU all-gather carries."""
         if out is None:
@@ -320,16 +330,26 @@ class WalkController:
         out.copy_(self.rows)
         return out
 
-    def capture_steps(self, n_steps: int, sched=None):
+    def capture_steps(self, n_steps: int, sched=None, sim_batch: int = None):
         """Capture n_steps pipelined env steps (walking reference update, TSID tick, sim step on the second stream)
         in ONE HIP graph and return it; graph.replay() then enqueues all of them with a single launch instead of
         ~8 host calls per step - what bounds small batches (512-1024 envs per GPU: the strong split of 4096 walkers
         over 4-8 GPUs).  The schedule's clock lives on the device (self.t_device, advanced inside the graph); results
-        are bit-identical to the same number of step_pipelined() calls.  The sim state is valid after sync_sim()."""
+        are bit-identical to the same number of step_pipelined() calls with the same number of sim steps per launch (float32:
+        a different number of sim steps per launch agrees to rounding only, include/tsidb.h tsidb_sim_batch).  The sim state
+        is valid after sync_sim().
+        sim_batch = sim steps per launch INSIDE the graph (default: as in eager mode).  A graph ends with a join, so the
+        sim batch still to run after the last tick runs alone; measured (tools/r03_graph.sh, 512 envs): eager 6.64 M
+        env-steps/s; 16 steps per graph 5.2 / 5.5 / 5.2 M with 1 / 2 / 8 sim steps per launch, 64 steps per graph 5.8 / 6.0 /
+        6.4 M - replaying a graph never beats the eager pipeline here."""
         if getattr(self.conf, "closed_loop", False) or not getattr(self.conf, "sim_enabled", True):
             raise _lib.TsidbError("capture_steps uses the open-loop pipeline (step_pipelined)")
         dt = self.conf.dt
         self.sync_sim()   # the state saved below must include the sim stage a previous step_pipelined() left in flight
+        self._ensure_pipe()   # (the ring sized for the eager batch: it is not rebuilt, and the graph's pointers stay valid, afterwards)
+        batch_keep = self.sim_batch
+        if sim_batch is not None:
+            self.sim_batch = max(1, min(int(sim_batch), len(self._pipe["q"]) // 2))
         self.t_device = torch.full((1,), self.t, dtype=torch.float64, device=self.device)   # float64 whatever the path's dtype
         # warm up outside the capture (lazy kernel loads, cached contiguous tables), then rewind the state
         keep = {k: getattr(self, k).clone() for k in ("q", "v", "qpos", "qvel", "qacc_warmstart", "com_ref", "posture_ref",
@@ -358,12 +378,14 @@ class WalkController:
                 self.t_device += dt
             self.sync_sim()                 # join the sim stream: the graph ends with every kernel done
         self._pipe["done"] = [None] * len(self._pipe["q"])
+        self.sim_batch = batch_keep
         self.t = t_keep                     # the capture advanced the host clock without running anything
 
         outer = self
 
         class _Graph:
             steps = n_steps
+            keep = (self._pipe["qring"], self._pipe["vring"], self._pipe["stream"])   # what the captured kernels point at
 
             def replay(self_inner):
                 g.replay()
