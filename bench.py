@@ -222,7 +222,13 @@ def run_workload(a, dev, rank, world, n, with_gather=True):
     # sim t (the reference couples them one way, main.py:192-195): WalkController.step_pipelined() leaves
     # sim(t) running on a second HIP stream while tick(t+1) runs on the first.
     overlap = not a.no_overlap and not getattr(a, "closed_loop", False)
-    s_tick = torch.cuda.current_stream(dev)
+    # the pipelined loop runs on the stream the library recommends (WalkController.tick_stream: for up to 512 envs the tick and
+    # the sim stream sit on disjoint halves of the CUs); everything of this workload from here on is enqueued on it
+    use_lib_stream = overlap and not getattr(a, "graph", 0) and os.environ.get("TSIDB_BENCH_TICK_STREAM", "1") == "1"
+    s_tick = wc.tick_stream if use_lib_stream else torch.cuda.current_stream(dev)   # (graph capture brings its own stream)
+    torch.cuda.current_stream(dev).synchronize()
+    _stream_ctx = torch.cuda.stream(s_tick)
+    _stream_ctx.__enter__()
     # N > 1: the all-gather of step t's rows runs on a third stream from a two-slot snapshot, so the
     # collective's latency is off the tick stream's critical path (the next tick overwrites the rows)
     side_gather = with_gather and world > 1 and not a.sync_gather
@@ -347,6 +353,8 @@ def run_workload(a, dev, rank, world, n, with_gather=True):
              "base_height_min_m": float(wc.q[:, 2].min())}
     res = dict(el=el, tick_ms=tick_ms, sim_ms=sim_ms, stats=stats, pre=pre, overlap=overlap, side_gather=side_gather,
                graph_steps=graph_steps)
+    torch.cuda.synchronize()
+    _stream_ctx.__exit__(None, None, None)
     return res, wc, sched, (pre + a.warmup + a.steps) * conf.dt
 
 

@@ -76,9 +76,21 @@ int tsidb_set_refs(tsidb_handle h, const void *com_ref, const void *posture_ref,
  * per env: the throughput-optimal shape once the batch fills the GPU) or 2 (collision phase on a second wavefront beside the
  * unconstrained dynamics: shorter step latency for small batches).  Default: 2 for up to 384 envs, else 1.  Bit-identical.
  * TSIDB_OPT_LDS_PAD (diagnostic): bytes of unused dynamic LDS added to every k_tick / k_sim workgroup (0 .. 40960) - lowers the
- * number of resident workgroups per CU, for occupancy measurements; default 0. */
-enum { TSIDB_OPT_SIM_WAVES = 1, TSIDB_OPT_LDS_PAD = 2 };
+ * number of resident workgroups per CU, for occupancy measurements; default 0.
+ * TSIDB_OPT_CU_SPLIT: whether tsidb_stream_create hands out streams on disjoint halves of the CUs: 1 always, 0 never, -1 (default)
+ * for up to 512 envs. */
+enum { TSIDB_OPT_SIM_WAVES = 1, TSIDB_OPT_LDS_PAD = 2, TSIDB_OPT_CU_SPLIT = 3 };
 int tsidb_set_option(tsidb_handle h, int option, int value);
+
+/* HIP streams for the pipelined step (tick of step t+1 on one stream beside the sim of step t on another; the reference couples
+ * the two stages one way, main.py:119-129 vs :192-195).  While every wavefront of both kernels is resident at once (up to 512
+ * envs: 2 x 512 wavefronts on 1024 SIMDs) the two kernels slow each other down when they share CU groups - k_tick 54 us alone,
+ * 70 us beside a running k_sim - so the streams handed out here are restricted to disjoint halves of the device's CUs
+ * (hipExtStreamCreateWithCUMask): + 11-14 % env-steps/s at 256 / 512 envs; above 512 envs (each kernel alone fills more than
+ * half of the SIMDs) plain streams are returned.  role: TSIDB_STREAM_TICK / TSIDB_STREAM_SIM.  Results do not depend on it. */
+enum { TSIDB_STREAM_TICK = 0, TSIDB_STREAM_SIM = 1 };
+int tsidb_stream_create(tsidb_handle h, int role, void **stream);
+int tsidb_stream_destroy(tsidb_handle h, void *stream);
 
 /* reference point of the CoP force task (legacy/biped.py:79-80 copTask; params[W_COP] != 0): cop_ref [N,3], world
  * frame; written by tsidb_reset (midpoint of the soles on the floor).  The pointer is remembered, not copied. */

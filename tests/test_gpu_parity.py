@@ -726,6 +726,31 @@ def test_step_pipelined_equals_step(batch, dtype):
         c.step_pipelined()
 
 
+def test_pipeline_on_the_library_streams():
+    """WalkController.tick_stream / the sim stream from tsidb_stream_create (for up to 512 envs: disjoint halves of the CUs,
+    hipExtStreamCreateWithCUMask): the pipelined loop on them gives the serial step()'s results bit for bit; the option
+    TSIDB_OPT_CU_SPLIT switches the split off."""
+    a, b, c = make(96, reference_quirks=False), make(96, reference_quirks=False), make(96, reference_quirks=False)
+    from tsid_control_amd import _lib
+    _lib.check(c._L, c._h, c._L.tsidb_set_option(c._h, 3, 0), "tsidb_set_option(cu_split)")   # plain streams
+    for w in (a, b, c):
+        perturb(w, 5)
+    for w in (b, c):
+        with torch.cuda.stream(w.tick_stream):
+            for _ in range(25):
+                w.step_pipelined()
+            w.sync_sim()
+        w.tick_stream.synchronize()
+    for _ in range(25):
+        a.step()
+    torch.cuda.synchronize()
+    assert b.tick_stream.cuda_stream != b._pipe["stream"].cuda_stream
+    for k in ("q", "v", "tau", "dv", "f", "status", "obs", "qpos", "qvel", "qacc_warmstart", "ncon", "con_pairs", "info"):
+        assert torch.equal(getattr(a, k), getattr(b, k)) and torch.equal(getattr(a, k), getattr(c, k)), k
+    with pytest.raises(Exception, match="role"):
+        _lib.check(a._L, a._h, a._L.tsidb_stream_create(a._h, 7, __import__("ctypes").byref(__import__("ctypes").c_void_p())), "tsidb_stream_create")
+
+
 def test_step_pipelined_mixed_with_reset_and_env_params():
     """reset() / step() / sim_step() / set_env_params() wait for the sim stage that
     step_pipelined() left on the side stream - mixing the entry points (the RL pattern: partial reset

@@ -638,6 +638,7 @@ struct tsidb_ctx {
   int device = 0, dtype = 0, num_envs = 0;
   int sim_waves = 1; // wavefronts per env in k_sim (tsidb_set_option)
   unsigned lds_pad = 0; // diagnostic: unused dynamic LDS per workgroup of k_tick / k_sim (occupancy experiments)
+  int cu_split = -1;    // tsidb_stream_create: tick and sim streams on disjoint halves of the CUs (-1 = up to 512 envs)
   Blob blob;
   std::vector<double> params;
   void *d_model = nullptr, *d_hull = nullptr, *d_box = nullptr;
@@ -1073,8 +1074,34 @@ int tsidb_set_option(tsidb_handle h, int option, int value) {
   if (!h) return -1;
   if (option == TSIDB_OPT_SIM_WAVES && (value == 1 || value == 2)) { h->sim_waves = value; return 0; }
   if (option == TSIDB_OPT_LDS_PAD && value >= 0 && value <= 40960) { h->lds_pad = (unsigned)value; return 0; }
+  if (option == TSIDB_OPT_CU_SPLIT && value >= -1 && value <= 1) { h->cu_split = value; return 0; }
   h->err = "tsidb_set_option: unknown option or value";
   return 1;
+}
+
+int tsidb_stream_create(tsidb_handle h, int role, void **stream) {
+  GUARD_BEGIN
+  if (!stream || (role != TSIDB_STREAM_TICK && role != TSIDB_STREAM_SIM)) throw std::string("tsidb_stream_create: role must be TSIDB_STREAM_TICK or TSIDB_STREAM_SIM");
+  hipStream_t s = nullptr;
+  const bool split = h->cu_split == 1 || (h->cu_split < 0 && h->num_envs <= 512);
+  if (split) {
+    hipDeviceProp_t prop;
+    HIP_OK(hipGetDeviceProperties(&prop, h->device));
+    const int ncu = prop.multiProcessorCount, half = ncu / 2;
+    std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
+    for (int c = role == TSIDB_STREAM_TICK ? 0 : half; c < (role == TSIDB_STREAM_TICK ? half : ncu); c++) mask[(size_t)c / 32] |= 1u << (c % 32);
+    HIP_OK(hipExtStreamCreateWithCUMask(&s, (uint32_t)mask.size(), mask.data()));
+  } else {
+    HIP_OK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  }
+  *stream = s;
+  GUARD_END
+}
+
+int tsidb_stream_destroy(tsidb_handle h, void *stream) {
+  GUARD_BEGIN
+  if (stream) HIP_OK(hipStreamDestroy((hipStream_t)stream));
+  GUARD_END
 }
 
 int tsidb_set_cop_ref(tsidb_handle h, const void *cop_ref) {

@@ -112,6 +112,9 @@ class WalkController:
     def __del__(self):
         try:
             if self._h:
+                for _, hs in getattr(self, "_streams", {}).values():
+                    self._L.tsidb_stream_destroy(self._h, hs)
+                self._streams = {}
                 self._L.tsidb_destroy(self._h)
                 self._h = C.c_void_p()
         except Exception:
@@ -284,8 +287,13 @@ class WalkController:
         P = self._pipe
         par = P["par"]
         P["par"] = (par + 1) % len(P["q"])
-        if P["done"][par] is not None:
-            cur.wait_event(P["done"][par])     # the sim that read this slot 2 * sim_batch steps ago
+        ev = P["done"][par]                    # the sim batch that read this slot 2 * sim_batch steps ago
+        lw = P.get("last_wait")
+        if ev is not None and not (lw is not None and lw[0] == cur.cuda_stream and lw[1] is ev):
+            # (once per batch: the slots of one batch share its event, and a cross-stream wait is a barrier packet that costs
+            #  the tick stream ~10 us each - at 512 envs a fifth of the step when it was issued before every tick)
+            cur.wait_event(ev)
+            P["last_wait"] = (cur.cuda_stream, ev)   # (the reference keeps the event alive: no id reuse)
         if events:
             events[0].record(cur)
         # the tick writes the TSID state it ends on into the slot as well (two copy kernels less on this stream); walk =
@@ -302,6 +310,27 @@ class WalkController:
             self._flush_sims(events)
         self.t += self.conf.dt
         return self.tau, self.q, self.v, self.status, self.obs
+
+    def _lib_stream(self, role):
+        """tsidb_stream_create: the stream the library recommends for the tick (role 0) / the sim (role 1) of the pipelined
+        step - on disjoint halves of the CUs for up to 512 envs (include/tsidb.h), plain streams above"""
+        st = getattr(self, "_streams", None)
+        if st is None:
+            st = self._streams = {}
+        if role not in st:
+            hs = C.c_void_p()
+            _lib.check(self._L, self._h, self._L.tsidb_stream_create(self._h, int(role), C.byref(hs)), "tsidb_stream_create")
+            st[role] = (torch.cuda.ExternalStream(hs.value, device=self.device), hs)
+        return st[role][0]
+
+    @property
+    def tick_stream(self):
+        """The stream to run the pipelined loop on: `with torch.cuda.stream(wc.tick_stream): wc.step_pipelined(...)`.  For up
+        to 512 envs it is restricted to one half of the CUs and the sim stream to the other (the two kernels slow each other
+        down by a quarter when they share CU groups: +11-14 % env-steps/s at 256 / 512 envs); otherwise an ordinary stream.
+        Optional - step_pipelined() works on any current stream; the sim stream is paired with this one only if the FIRST
+        step_pipelined() runs on it."""
+        return self._lib_stream(0)
 
     def _ensure_pipe(self):
         """the second stream and the ring of snapshot slots step_pipelined() hands the TSID state to the sim stages through;
@@ -320,7 +349,13 @@ class WalkController:
         K = need
         qring = torch.empty(K, *self.q.shape, dtype=self.dtype, device=self.device)   # one allocation: a batch of sim
         vring = torch.empty(K, *self.v.shape, dtype=self.dtype, device=self.device)   # stages names its slots by number
-        self._pipe = dict(stream=torch.cuda.Stream(device=self.device), par=0, done=[None] * K, pending=[], qring=qring, vring=vring,
+        # the sim stream: the library's (on the other half of the CUs for up to 512 envs) when the loop runs on
+        # self.tick_stream, an ordinary one otherwise - a CU-masked stream is a BLOCKING stream (hipExtStreamCreateWithCUMask
+        # takes no flags), and beside work on the legacy default stream it would serialise with it
+        ts = getattr(self, "_streams", {}).get(0)
+        on_tick = ts is not None and torch.cuda.current_stream(self.device).cuda_stream == ts[0].cuda_stream
+        self._pipe = dict(stream=self._lib_stream(1) if on_tick else torch.cuda.Stream(device=self.device),
+                          par=0, done=[None] * K, pending=[], qring=qring, vring=vring,
                           q=[qring[k] for k in range(K)], v=[vring[k] for k in range(K)])
 
     def gather_rows(self, out=None):
@@ -371,6 +406,7 @@ class WalkController:
         self.t_device.fill_(self.t)
         self._pipe["done"] = [None] * len(self._pipe["q"])   # no event from outside the capture may be waited on inside it
         self._pipe["par"] = 0
+        self._pipe["last_wait"] = None
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             for _ in range(n_steps):
@@ -378,6 +414,7 @@ class WalkController:
                 self.t_device += dt
             self.sync_sim()                 # join the sim stream: the graph ends with every kernel done
         self._pipe["done"] = [None] * len(self._pipe["q"])
+        self._pipe["last_wait"] = None
         self.sim_batch = batch_keep
         self.t = t_keep                     # the capture advanced the host clock without running anything
 
