@@ -292,7 +292,8 @@ class WalkController:
         if ev is not None and not (lw is not None and lw[0] == cur.cuda_stream and lw[1] is ev):
             # (once per batch: the slots of one batch share its event, and a cross-stream wait is a barrier packet that costs
             #  the tick stream ~10 us each - at 512 envs a fifth of the step when it was issued before every tick)
-            cur.wait_event(ev)
+            if torch.cuda.is_current_stream_capturing() or not ev.query():   # (already complete: no packet)
+                cur.wait_event(ev)
             P["last_wait"] = (cur.cuda_stream, ev)   # (the reference keeps the event alive: no id reuse)
         if events:
             events[0].record(cur)
