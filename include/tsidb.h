@@ -81,6 +81,8 @@ int tsidb_set_refs(tsidb_handle h, const void *com_ref, const void *posture_ref,
  * for up to 512 envs. */
 enum { TSIDB_OPT_SIM_WAVES = 1, TSIDB_OPT_LDS_PAD = 2, TSIDB_OPT_CU_SPLIT = 3 };
 int tsidb_set_option(tsidb_handle h, int option, int value);
+int tsidb_get_option(tsidb_handle h, int option, int *value); /* the EFFECTIVE setting (TSIDB_OPT_CU_SPLIT: 1 if tsidb_stream_create
+                                                                * masks its streams for this handle's batch size) */
 
 /* HIP streams for the pipelined step (tick of step t+1 on one stream beside the sim of step t on another; the reference couples
  * the two stages one way, main.py:119-129 vs :192-195).  While every wavefront of both kernels is resident at once (up to 512

@@ -11,7 +11,7 @@ LIB_PATH = Path(os.environ.get("TSIDB_LIB_PATH", _HERE / "libtsidb.so"))
 
 SYMBOLS = ["tsidb_dims", "tsidb_create", "tsidb_destroy", "tsidb_last_error", "tsidb_set_params", "tsidb_set_refs", "tsidb_reset",
            "tsidb_tick", "tsidb_sim", "tsidb_step", "tsidb_rbd_terms", "tsidb_lds_bytes", "tsidb_walk_update", "tsidb_set_env_params", "tsidb_set_cop_ref",
-           "tsidb_reset_done", "tsidb_set_posture_bias", "tsidb_walk_plan", "tsidb_set_option", "tsidb_tick_walk", "tsidb_sim_batch", "tsidb_stream_create", "tsidb_stream_destroy"]
+           "tsidb_reset_done", "tsidb_set_posture_bias", "tsidb_walk_plan", "tsidb_set_option", "tsidb_tick_walk", "tsidb_sim_batch", "tsidb_stream_create", "tsidb_stream_destroy", "tsidb_get_option"]
 
 _libs = {}
 

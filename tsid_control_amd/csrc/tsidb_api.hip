@@ -1079,6 +1079,16 @@ int tsidb_set_option(tsidb_handle h, int option, int value) {
   return 1;
 }
 
+int tsidb_get_option(tsidb_handle h, int option, int *value) {
+  if (!h) return -1;
+  if (!value) { h->err = "tsidb_get_option: null value"; return 1; }
+  if (option == TSIDB_OPT_SIM_WAVES) { *value = h->sim_waves; return 0; }
+  if (option == TSIDB_OPT_LDS_PAD) { *value = (int)h->lds_pad; return 0; }
+  if (option == TSIDB_OPT_CU_SPLIT) { *value = (h->cu_split == 1 || (h->cu_split < 0 && h->num_envs <= 512)) ? 1 : 0; return 0; }
+  h->err = "tsidb_get_option: unknown option";
+  return 1;
+}
+
 int tsidb_stream_create(tsidb_handle h, int role, void **stream) {
   GUARD_BEGIN
   if (!stream || (role != TSIDB_STREAM_TICK && role != TSIDB_STREAM_SIM)) throw std::string("tsidb_stream_create: role must be TSIDB_STREAM_TICK or TSIDB_STREAM_SIM");

@@ -113,7 +113,8 @@ class WalkController:
         try:
             if self._h:
                 for _, hs in getattr(self, "_streams", {}).values():
-                    self._L.tsidb_stream_destroy(self._h, hs)
+                    if hs is not None:
+                        self._L.tsidb_stream_destroy(self._h, hs)
                 self._streams = {}
                 self._L.tsidb_destroy(self._h)
                 self._h = C.c_void_p()
@@ -312,6 +313,31 @@ class WalkController:
         self.t += self.conf.dt
         return self.tau, self.q, self.v, self.status, self.obs
 
+    def _streams_overlap(self, sa, sb):
+        """True if work on the two streams really runs concurrently.  HIP multiplexes its streams onto a few hardware queues
+        (GPU_MAX_HW_QUEUES, 4 by default) and two streams - even two created one after the other - can share one, in which
+        case tick and sim run one after the other and the pipelined step loses its overlap without any error
+        (tools/stream_overlap_probe.py).  Probe: a short device-side spin on each, timed together against one alone."""
+        if os.environ.get("TSIDB_NO_STREAM_PROBE") == "1" or not hasattr(torch.cuda, "_sleep") or torch.cuda.is_current_stream_capturing():
+            return True
+        import time
+        try:
+            def spin(streams, cycles=600000):   # ~0.25 ms at 2.4 GHz
+                torch.cuda.synchronize(self.device)
+                t0 = time.perf_counter()
+                for st in streams:
+                    with torch.cuda.stream(st):
+                        torch.cuda._sleep(cycles)
+                for st in streams:
+                    st.synchronize()
+                return time.perf_counter() - t0
+            spin([sa, sb], 1000)                 # (first use of the kernel on these streams)
+            one = min(spin([sa]), spin([sb]))
+            both = min(spin([sa, sb]), spin([sa, sb]))
+            return both < 1.6 * one
+        except Exception:
+            return True
+
     def _lib_stream(self, role):
         """tsidb_stream_create: the stream the library recommends for the tick (role 0) / the sim (role 1) of the pipelined
         step - on disjoint halves of the CUs for up to 512 envs (include/tsidb.h), plain streams above"""
@@ -319,9 +345,20 @@ class WalkController:
         if st is None:
             st = self._streams = {}
         if role not in st:
-            hs = C.c_void_p()
-            _lib.check(self._L, self._h, self._L.tsidb_stream_create(self._h, int(role), C.byref(hs)), "tsidb_stream_create")
-            st[role] = (torch.cuda.ExternalStream(hs.value, device=self.device), hs)
+            split = C.c_int(0)
+            _lib.check(self._L, self._h, self._L.tsidb_get_option(self._h, 3, C.byref(split)), "tsidb_get_option(cu_split)")
+            for r in (0, 1):   # (both at once)
+                if split.value:
+                    hs = C.c_void_p()
+                    _lib.check(self._L, self._h, self._L.tsidb_stream_create(self._h, r, C.byref(hs)), "tsidb_stream_create")
+                    st[r] = (torch.cuda.ExternalStream(hs.value, device=self.device), hs)
+                else:
+                    st[r] = (torch.cuda.Stream(device=self.device), None)   # no CU split for this batch size: torch's pool
+            if not split.value:
+                for _ in range(6):               # a pair that shares a hardware queue would serialise tick and sim
+                    if self._streams_overlap(st[0][0], st[1][0]):
+                        break
+                    st[1] = (torch.cuda.Stream(device=self.device), None)
         return st[role][0]
 
     @property
@@ -355,7 +392,15 @@ class WalkController:
         # takes no flags), and beside work on the legacy default stream it would serialise with it
         ts = getattr(self, "_streams", {}).get(0)
         on_tick = ts is not None and torch.cuda.current_stream(self.device).cuda_stream == ts[0].cuda_stream
-        self._pipe = dict(stream=self._lib_stream(1) if on_tick else torch.cuda.Stream(device=self.device),
+        if on_tick:
+            sim_stream = self._lib_stream(1)
+        else:
+            cur = torch.cuda.current_stream(self.device)
+            for _ in range(6):                   # (a stream that shares the current one's hardware queue would serialise)
+                sim_stream = torch.cuda.Stream(device=self.device)
+                if self._streams_overlap(cur, sim_stream):
+                    break
+        self._pipe = dict(stream=sim_stream,
                           par=0, done=[None] * K, pending=[], qring=qring, vring=vring,
                           q=[qring[k] for k in range(K)], v=[vring[k] for k in range(K)])
 
