@@ -232,7 +232,17 @@ def run_workload(a, dev, rank, world, n, with_gather=True):
     # N > 1: the all-gather of step t's rows runs on a third stream from a two-slot snapshot, so the
     # collective's latency is off the tick stream's critical path (the next tick overwrites the rows)
     side_gather = with_gather and world > 1 and not a.sync_gather
-    s_comm = torch.cuda.Stream(device=dev) if side_gather else None
+    s_comm = None
+    if side_gather:
+        # a third stream for the collective that shares a hardware queue with neither of the other two (HIP multiplexes
+        # streams onto a few queues; WalkController._streams_overlap)
+        if overlap:
+            wc._ensure_pipe()
+        others = [s_tick] + ([wc._pipe["stream"]] if getattr(wc, "_pipe", None) else [])
+        for _ in range(6):
+            s_comm = torch.cuda.Stream(device=dev)
+            if all(wc._streams_overlap(o, s_comm) for o in others):
+                break
     snap_buf = [torch.empty(n, wc.gather_width, dtype=wc.dtype, device=dev) for _ in range(2)] if side_gather else None
     comm_done = [None, None]
 
