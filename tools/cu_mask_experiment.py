@@ -35,6 +35,14 @@ elif layout == "prio_sim":   # sim stream at high priority
     s_tick, s_sim = torch.cuda.Stream(priority=0), torch.cuda.Stream(priority=-1)
 elif layout == "halves":
     s_tick, s_sim = masked_stream([0xFFFFFFFF] * 4 + [0] * 4), masked_stream([0] * 4 + [0xFFFFFFFF] * 4)
+elif layout.startswith("a") and layout[1:].isdigit():   # the first k CUs for the tick, the rest for the sim
+    k = int(layout[1:])
+    def bits(lo, hi):
+        w = [0] * 8
+        for c in range(lo, hi):
+            w[c // 32] |= 1 << (c % 32)
+        return w
+    s_tick, s_sim = masked_stream(bits(0, k)), masked_stream(bits(k, 256))
 elif layout == "alt32":
     s_tick, s_sim = masked_stream([0xFFFFFFFF, 0] * 4), masked_stream([0, 0xFFFFFFFF] * 4)
 else:
