@@ -1100,10 +1100,13 @@ int tsidb_stream_create(tsidb_handle h, int role, void **stream) {
     const int ncu = prop.multiProcessorCount, half = ncu / 2;
     std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
     for (int c = role == TSIDB_STREAM_TICK ? 0 : half; c < (role == TSIDB_STREAM_TICK ? half : ncu); c++) mask[(size_t)c / 32] |= 1u << (c % 32);
-    HIP_OK(hipExtStreamCreateWithCUMask(&s, (uint32_t)mask.size(), mask.data()));
-  } else {
-    HIP_OK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    if (hipExtStreamCreateWithCUMask(&s, (uint32_t)mask.size(), mask.data()) != hipSuccess) {
+      (void)hipGetLastError(); // CU masking not available here: an ordinary stream, and no further attempts for this handle
+      s = nullptr;
+      h->cu_split = 0;
+    }
   }
+  if (!s) HIP_OK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
   *stream = s;
   GUARD_END
 }

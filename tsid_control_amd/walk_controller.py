@@ -354,11 +354,12 @@ class WalkController:
                     st[r] = (torch.cuda.ExternalStream(hs.value, device=self.device), hs)
                 else:
                     st[r] = (torch.cuda.Stream(device=self.device), None)   # no CU split for this batch size: torch's pool
-            if not split.value:
-                for _ in range(6):               # a pair that shares a hardware queue would serialise tick and sim
-                    if self._streams_overlap(st[0][0], st[1][0]):
-                        break
-                    st[1] = (torch.cuda.Stream(device=self.device), None)
+            for _ in range(6):                   # a pair that shares a hardware queue would serialise tick and sim
+                if self._streams_overlap(st[0][0], st[1][0]):
+                    break
+                if st[1][1] is not None:
+                    self._L.tsidb_stream_destroy(self._h, st[1][1])
+                st[1] = (torch.cuda.Stream(device=self.device), None)
         return st[role][0]
 
     @property
