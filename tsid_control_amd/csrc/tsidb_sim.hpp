@@ -292,10 +292,18 @@ __device__ __forceinline__ bool chol26_rank1(T (&a)[NV], T &rdv, T xv, T sigma, 
 
 // out = M * x for the lane's dof (x in LDS)
 template <typename T> __device__ __forceinline__ T mulM(const SimLds<T> &L, const T *x, int lane) {
-  T s = 0;
-  if (lane < NV)
-    for (int j = 0; j < NV; j++) s += L.M[lane * LDM + j] * x[j];
-  return s;
+  T s = 0, s1 = 0, s2 = 0, s3 = 0; // (four partial sums: a dependent float64 FMA waits for its predecessor)
+  if (lane < NV) {
+    const T *Mr = &L.M[lane * LDM];
+#pragma unroll
+    for (int j = 0; j < NV; j += 4) {
+      s += Mr[j] * x[j];
+      if (j + 1 < NV) s1 += Mr[j + 1] * x[j + 1];
+      if (j + 2 < NV) s2 += Mr[j + 2] * x[j + 2];
+      if (j + 3 < NV) s3 += Mr[j + 3] * x[j + 3];
+    }
+  }
+  return (s + s1) + (s2 + s3);
 }
 
 // mju_makeFrame: tangents of a contact frame from its normal (t1 from y unless |n_y| >= 0.5, t2 = n x t1)

@@ -848,7 +848,12 @@ __device__ __forceinline__ void tick_qp(const DevModel<T> &m, TickLds<T> &L, QpC
       for (int idx = lane; idx < 6 * 12 * NS; idx += WAVE) {
         const int cl = idx / (12 * NS), rem = idx % (12 * NS), s2 = rem / 12, e = rem % 12;
         T sacc = 0;
-        for (int b = 0; b <= e; b++) sacc += m.Jf0[b][e] * L.Dyn[cl * LDD + NV + 12 * s2 + b];
+        // (fixed trip count, predicated: with the lane-dependent bound every term waited for its own global load of Jf0)
+#pragma unroll
+        for (int b = 0; b < 12; b++) {
+          const T term = m.Jf0[b][e] * L.Dyn[cl * LDD + NV + 12 * s2 + b];
+          sacc = b <= e ? sacc + term : sacc;
+        }
         fcl[idx] = sacc;
       }
       TSIDB_SYNC1();
@@ -1274,8 +1279,19 @@ __device__ __forceinline__ void tsid_tick_env(const DevModel<T> &m, TickLds<T> &
   }
   T tau2 = 0;
   if (lane < NA) {
-    T t = L.h[6 + lane];
-    for (int e = 0; e < n; e++) t += L.Dyn[(6 + lane) * LDD + e] * L.x[e];
+    // (compile-time length, four partial sums: the run-time loop with one accumulator waited out an LDS round trip and a
+    //  dependent float64 FMA per term - 38 to 50 of them)
+    constexpr int NNc = NV + 12 * NS;
+    const T *Dr = &L.Dyn[(6 + lane) * LDD];
+    T t = L.h[6 + lane], t1 = 0, t2 = 0, t3 = 0;
+#pragma unroll
+    for (int e = 0; e < NNc; e += 4) {
+      t += Dr[e] * L.x[e];
+      if (e + 1 < NNc) t1 += Dr[e + 1] * L.x[e + 1];
+      if (e + 2 < NNc) t2 += Dr[e + 2] * L.x[e + 2];
+      if (e + 3 < NNc) t3 += Dr[e + 3] * L.x[e + 3];
+    }
+    t = (t + t1) + (t2 + t3);
     if (m.params[P_FRICTION_COMP] != 0) { // Coulomb-friction feed-forward along the commanded joint velocity
       const T vn = L.vs[6 + lane] + m.params[P_DT] * L.x[6 + lane], sat = vn * T(20);
       t += m.params[P_FRICTION_COMP] * (sat > 1 ? T(1) : (sat < -1 ? T(-1) : sat));
