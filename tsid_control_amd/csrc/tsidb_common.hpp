@@ -367,11 +367,19 @@ template <typename T> __device__ __forceinline__ void cross_mf(const T *v, const
 // has to be waited for - only the compiler has to keep the order; __syncthreads() additionally drains every outstanding LDS
 // AND global access (s_waitcnt vmcnt(0) lgkmcnt(0)) at each of the ~60 hand-overs of a step.  Measured (round 3,
 // -DTSIDB_WAVE_SYNC, tools/r03_ab.sh): no difference - 16.5 M env-steps/s at 4096 envs and 6.6 M at 512 either way, nothing is
-// in flight at those points that the next phase does not need - so the default stays the plain barrier.
+// in flight at those points that the next phase does not need - so the default stays the plain barrier.  With the fences
+// restricted to the LDS address space (-DTSIDB_WAVE_SYNC_LOCAL: global loads may then be scheduled across the hand-overs)
+// + 0.3-0.5 %, consistently but too little to change the synchronisation the tests have run on.
 __device__ __forceinline__ void wave_sync() {
+#ifdef TSIDB_WAVE_SYNC_LOCAL // fences for the LDS address space only: global loads may be scheduled across the hand-over
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+#else
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
 }
 #ifdef TSIDB_WAVE_SYNC
 #define TSIDB_SYNC1() wave_sync()
