@@ -103,6 +103,9 @@ __device__ __forceinline__ void rbd_terms(const DevModel<T> &m, TickLds<T> &L, i
   int jchn[7];
 #pragma unroll
   for (int d = 0; d < 7; d++) jchn[d] = lane < NJ ? m.pin_chain[lane][d] : -1;
+  // (the frames' parent joints and their ancestor masks too: a dependent pair of loads, needed after the tree passes)
+  const int fpar0 = m.frame_parent[0], fpar1 = m.frame_parent[1];
+  const unsigned fanc0 = m.pin_anc[fpar0], fanc1 = m.pin_anc[fpar1];
 #pragma unroll
   for (int i = 0; i < 6; i++) { Vj[i] = 0; Aj[i] = 0; Sj[i] = 0; }
 #pragma unroll
@@ -236,7 +239,7 @@ __device__ __forceinline__ void rbd_terms(const DevModel<T> &m, TickLds<T> &L, i
   TSIDB_LAP(31);
   // ---- frames (lanes 0,1): placement, velocity, classical drift acceleration (LOCAL)
   if (lane < 2) {
-    const int f = lane, jf = m.frame_parent[f];
+    const int f = lane, jf = f == 0 ? fpar0 : fpar1;
     const T *P = m.frame_place[f];
     T Rf[9], pf[3];
     mat3mul(K.R[jf], P, Rf);
@@ -282,7 +285,7 @@ __device__ __forceinline__ void rbd_terms(const DevModel<T> &m, TickLds<T> &L, i
 #pragma unroll
     for (int f = 0; f < 2; f++) {
       T col[6] = {0, 0, 0, 0, 0, 0};
-      if ((m.pin_anc[m.frame_parent[f]] >> jk) & 1u) {
+      if (((f == 0 ? fanc0 : fanc1) >> jk) & 1u) {
         T wxp[3], lin[3];
         cross3(&K.S[k][3], K.fp[f], wxp);
 #pragma unroll
