@@ -452,7 +452,54 @@ def secondary_runs(a, dev):
                      "hip_graph_steps_per_launch": res["graph_steps"], "last_step_stats": res["stats"]}
         del wc
         torch.cuda.empty_cache()
+    if a.dtype == "f64":
+        out["cfg3_walk_4096_device_episodes"] = device_episodes_run(dev, 4096, max(a.secondary_steps * 20, 4000))
     return out
+
+
+def device_episodes_run(dev, n, steps):
+    """The pipelined walking loop with the episode lifecycle on the device: plans built by tsidb_walk_plan
+    (short paths, so that episodes end often), every 50 steps the envs whose plan is walked to the end are marked done and
+    tsidb_reset_done + a new plan restart them - no host synchronisation inside the timed region."""
+    from tsid_control_amd import RobotConfig, WalkController
+    from tsid_control_amd.walk_planner import WalkSchedule, op3_walking_conf, op3_walking_posture
+    conf = op3_walking_conf(RobotConfig())
+    conf.reference_quirks = False
+    wc = WalkController(conf, num_envs=n, device=dev)
+    wc.set_posture_bias(op3_walking_posture())
+    sched = WalkSchedule.on_device(wc, seed=3, K=40, scale_range=(0.02, 0.08))   # 2-8 steps per episode: 1000-2500 ticks
+    resets = torch.zeros((), dtype=torch.int64, device=dev)
+    failed = torch.zeros((), dtype=torch.int64, device=dev)
+    flagged = torch.zeros((), dtype=torch.int64, device=dev)
+
+    def loop(k):
+        for i in range(k):
+            wc.step_pipelined(walk=(sched, wc.t))
+            if i % 50 == 49:
+                over = (wc.t - sched.t_offset.double()) > (sched.t_start + sched.nsteps.double() * conf.step_duration + 1.0)
+                wc.rows[:, wc.NOBS + 1] = torch.maximum(wc.rows[:, wc.NOBS + 1], over.to(wc.dtype))
+                resets.add_((wc.rows[:, wc.NOBS + 1] != 0).sum())
+                failed.add_((wc.status != 0).sum())
+                wc.sync_sim()
+                flagged.add_(((wc.info[:, 3] & (1 | 2 | 4 | 32)) != 0).sum())
+                wc.reset_done(sched, t=wc.t)
+        wc.sync_sim()
+
+    with torch.cuda.stream(wc.tick_stream):
+        loop(700)
+        torch.cuda.synchronize()
+        resets.zero_(); failed.zero_(); flagged.zero_()
+        t0 = time.perf_counter()
+        loop(steps)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+    res = {"workload": f"cfg3: {n} OP3 walkers, plans built on the device, episodes restarted on the device (reset_done + new plan every 50 steps)",
+           "value": n * steps / el, "unit": "env-steps/s", "steps": steps, "ms_per_step": 1e3 * el / steps, "k_tick_ms": None, "k_sim_ms": None,
+           "roofline": None, "episode_resets": int(resets), "failed_qp_samples": int(failed), "flagged_sim_samples": int(flagged),
+           "states_finite": bool(torch.isfinite(wc.q).all() and torch.isfinite(wc.qpos).all())}
+    del wc
+    torch.cuda.empty_cache()
+    return res
 
 
 def main():
