@@ -758,6 +758,7 @@ __device__ __forceinline__ void tick_qp(const DevModel<T> &m, TickLds<T> &L, QpC
   //   xr = L^-1 e_lane                    (column `lane` of L^-1 = row `lane` of J0 = L^-T)
   //   bc = L^-1 CE[lane][0:26]^T          (column `lane` of B = J0^T CE^T, lanes < p)
   constexpr int NN = NV + 12 * NS, PP = 6 + 6 * NS; // variables / equality constraints of this contact configuration
+  constexpr int NC = 6 * NS;                        // contact-motion equalities (they come first, see below)
   const int p = PP, n = NN;
   // B = J^T CE^T (NN x PP) is held by COLUMN, each column split over G lanes: lane c + PP g keeps rows
   // [g GS, (g + 1) GS) of column c in bs[0..GS).  (One whole column per lane - the first version - costs NN doubles in
@@ -780,8 +781,12 @@ __device__ __forceinline__ void tick_qp(const DevModel<T> &m, TickLds<T> &L, QpC
       T acc = -gi;
       T yv = 0;
       // CE row `col`: base dynamics rows come from Dyn, contact motion rows from the frame Jacobians
-      const bool isbase = col < 6;
-      const int crow = col < 6 ? col : 6 * slot_foot<T, NS>(L, (col - 6) / 6) + (col - 6) % 6;
+      // column order: the 6 NS contact-motion rows FIRST, then the six base-dynamics rows.  (tsid stacks the base dynamics
+      // first; the solution does not depend on the order the equalities enter the factorisation, only its rounding does.)
+      // A contact row has no force variables, so its column of B is zero below row NV and stays so while only contact
+      // columns are reflected: their reflectors are NV long instead of NN - a third of the QR's work in double support.
+      const bool isbase = col >= NC;
+      const int crow = isbase ? col - NC : 6 * slot_foot<T, NS>(L, col / 6) + col % 6;
 #pragma unroll
       for (int i = 0; i < NV; i++) {
         const T rdi = rdlane(rdv, i); // 1 / L[i][i] (lane i keeps it: 26 wave-uniform doubles held across these loops
@@ -813,8 +818,8 @@ __device__ __forceinline__ void tick_qp(const DevModel<T> &m, TickLds<T> &L, QpC
       }
       c2 = wave_sum(c2) + T(c.nslot) * m.Jf0_trace;
       if (bl) {
-        if (col < 6) ck += L.h[col];
-        else ck -= L.k.arhs[slot_foot<T, NS>(L, (col - 6) / 6)][(col - 6) % 6];
+        if (isbase) ck += L.h[col - NC];
+        else ck -= L.k.arhs[slot_foot<T, NS>(L, col / 6)][col % 6];
       }
       // rows of the dv block go to their group's lane
 #pragma unroll
@@ -936,11 +941,11 @@ __device__ __forceinline__ void tick_qp(const DevModel<T> &m, TickLds<T> &L, QpC
         }
       }
       // rows of the force block go to their group's lane
-      if (bl && col < 6) {
+      if (bl && col >= NC) {
 #pragma unroll
         for (int j = 0; j < GS; j++) {
           const int row = grp * GS + j;
-          if (row >= NV && row < NN) bs[j] = fcl[col * 12 * NS + row - NV];
+          if (row >= NV && row < NN) bs[j] = fcl[(col - NC) * 12 * NS + row - NV];
         }
       }
       TSIDB_SYNC1(); // (the sweep below writes the row buffer)
@@ -953,6 +958,7 @@ __device__ __forceinline__ void tick_qp(const DevModel<T> &m, TickLds<T> &L, QpC
 #pragma unroll
     for (int k = 0; k < PP; k++) {
       const int gk = k / GS, sk = k % GS; // the group and slot that hold row k (compile-time after unrolling)
+      const int RL = k < NC ? NV : NN;    // rows the reflector of column k reaches (exact zeros beyond, for a contact column)
       {
         // tail norm of column k: each of its lanes sums its own rows > k
         T sig_hi = 0, sig_all = 0;
@@ -980,8 +986,8 @@ __device__ __forceinline__ void tick_qp(const DevModel<T> &m, TickLds<T> &L, QpC
           for (int g = 0; g < G; g++) sbg[g] = 0;
           sbg[gk] = v0 * bs[sk];
 #pragma unroll
-          for (int i0 = k + 1; i0 < NN; i0 += 2) { // two reflector entries READ, then their four FMAs
-            const bool p1 = i0 + 1 < NN;
+          for (int i0 = k + 1; i0 < RL; i0 += 2) { // two reflector entries READ, then their four FMAs
+            const bool p1 = i0 + 1 < RL;
             const int i1 = p1 ? i0 + 1 : i0, g0 = i0 / GS, s0 = i0 % GS, g1 = i1 / GS, s1 = i1 % GS;
             const T u0 = rdlane(bs[s0], k + PP * g0), u1 = p1 ? rdlane(bs[s1], k + PP * g1) : T(0);
             asm volatile("" : "+v"(wj), "+v"(wj1), "+v"(sbg[g0]), "+v"(sbg[g1]) : "s"(u0), "s"(u1));
@@ -1009,8 +1015,8 @@ __device__ __forceinline__ void tick_qp(const DevModel<T> &m, TickLds<T> &L, QpC
 #pragma unroll
           for (int j = 0; j < GS; j++) asm volatile("" : "+v"(bs[j]));
 #pragma unroll
-          for (int i0 = k + 1; i0 < NN; i0 += 2) { // (column k's lanes are untouched until the loop ends: sg = 0 there)
-            const bool p1 = i0 + 1 < NN;
+          for (int i0 = k + 1; i0 < RL; i0 += 2) { // (column k's lanes are untouched until the loop ends: sg = 0 there)
+            const bool p1 = i0 + 1 < RL;
             const int i1 = p1 ? i0 + 1 : i0, g0 = i0 / GS, s0 = i0 % GS, g1 = i1 / GS, s1 = i1 % GS;
             const T u0 = rdlane(bs[s0], k + PP * g0), u1 = p1 ? rdlane(bs[s1], k + PP * g1) : T(0);
             // this pair's targets and the previous pair's last result are "changed": the previous FMAs come before, these after
