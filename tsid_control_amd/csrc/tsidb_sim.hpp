@@ -235,7 +235,10 @@ __device__ __forceinline__ void chol26_factor(T (&a)[NV], T &rdv, int lane, bool
 //                 of U on lane k: read back transposed from the parked copy (26 conflict-free ds_read_b64 per lane;
 //                 entries below the diagonal are exact zeros).
 // (The first version ran the second pass row-oriented from `a` alone: a dot product across lanes per pivot, i.e. two
-//  v_readlane + one FMA per ancestor PAIR - 780 instructions against 160.)
+//  v_readlane + one FMA per ancestor PAIR - 780 instructions against 160.  Measured and dropped, round 3: the branches'
+//  pivots dealt to two accumulators, alternating in program order - two independent mul -> v_readlane -> FMA chains instead of
+//  one through all 26 pivots: the Newton loop's factor + solves 39.5 k -> 38.5 k cycles over 3.3 iterations, not worth the
+//  compile-time order tables.)
 template <typename T>
 __device__ __forceinline__ T chol26_subst(const T (&a)[NV], const T *Up, T rdv, T rhs, int lane) {
   int ln = lane;
