@@ -137,32 +137,28 @@ def test_single_tick_f32_within_tolerance(oracle):
         st["tau"][e], st["dv"][e], st["f"][e], st["status"][e] = out["tau"], out["dv"], out["f"], out["status"]
     assert np.array_equal(wc.status.cpu().numpy(), st["status"])
     tau, dv = wc.tau.double().cpu().numpy(), wc.dv.double().cpu().numpy()
-    # rtol 1e-3, atol 1e-4 (observed: tau 8e-5 abs, dv 2e-5 abs).  The per-foot wrench meets the
-    # relative part only with atol 1e-3 (observed 9.7e-4 on 20 N components: the regularised force split is the
-    # worst-conditioned output of the QP)
+    # rtol 1e-3, atol 1e-4 for tau, dv and the per-foot wrench, as written.  (Until the equality QR
+    # took the contact-motion columns first - DESIGN.md section 7 - the wrench met it only with atol 1e-3: 9.7e-4 on 20 N
+    # components; with that order it is 1.4e-6 of the normal force.)
     assert np.allclose(tau, st["tau"], rtol=1e-3, atol=1e-4)
     assert np.allclose(dv, st["dv"], rtol=1e-3, atol=1e-4)
-    assert np.allclose(wrench(wc.f.double().cpu().numpy(), wc.params), wrench(st["f"], wc.params), rtol=1e-3, atol=1e-3)
+    assert np.allclose(wrench(wc.f.double().cpu().numpy(), wc.params), wrench(st["f"], wc.params), rtol=1e-3, atol=1e-4)
     assert diff(wc.q, st["q"]) < 1e-5 and diff(wc.v, st["v"]) < 1e-4
 
 
 def test_one_env_step_f32_against_section5(oracle):
     """The f32 path against BASELINE.md section 5 on ONE env step from identical inputs, 256 perturbed standing envs (VERDICT r2
     item 8) - what holds as written, and what holds only in an amended form, with the reason:
-      dv, next q, next v         as written (rtol 1e-3 / atol 1e-4; atol 1e-5): observed 2e-5, 3e-8, 4e-8
-      per-foot wrench T f        rtol 1e-3 with the absolute part SCALED BY THE FOOT'S LOAD: atol 1e-4 x max(f_z, 1 N).  The
-                                 split of a foot's wrench among its 4 corner forces is fixed only by the 1e-8 regularisation, so
-                                 every component carries an error proportional to the 20 N the foot carries, not to itself
-                                 (observed 9.4e-5 of f_z; a 0.09 N m yaw moment cannot be right to 1e-4 N m beside 20 N)
-      tau                        rtol 1e-3 / atol 1e-3: tau is the O(0.1) N m remainder of M_a dv + h_a - J_a^T f, three O(1) N m
-                                 terms, and inherits the wrench's 1e-4 relative error on that scale (observed 9.7e-4 in 2 envs of 256;
-                                 254 meet the section as written)
+      tau, dv, per-foot wrench,  as written (rtol 1e-3 / atol 1e-4; atol 1e-5): observed ratios to the tolerance 0.05, 0.06, 0.03
+      next q, next v             (wrench error 1.4e-6 of the normal force), 3e-8, 4e-8.  (tau and the wrench needed amended
+                                 tolerances - 9.4e-5 of f_z - until the equality QR took the contact-motion columns first,
+                                 DESIGN.md section 7: that order is the better-conditioned one in float32.)
       contact (geom, vertex) ids bit-exact where float32 can tell the lowest sole vertex from its neighbours: ties are taken
                                  within 2e-6 m in float32 (1e-9 in float64), so on near-flat soles the
                                  support vertex - and with it the neighbour list - may differ: >= 85 % of the envs identical
       next qpos, qvel            on the envs with identical contact lists: qpos atol 1e-5 as written (observed 1e-7); qvel atol
                                  5e-5, 99 % within 1e-5 - the contact rows are stiff (D ~ 1e6 against M ~ 1e-3 in H = M + J^T D J),
-                                 and dt x qacc carries float32's share of that conditioning (observed 1.9e-5 in one env)"""
+                                 and dt x qacc carries float32's share of that conditioning (observed 1.9e-5 in two envs)"""
     n = 256
     wc = make(n, "f32")
     perturb(wc, 4)
@@ -174,10 +170,8 @@ def test_one_env_step_f32_against_section5(oracle):
     assert np.allclose(g("dv"), st["dv"], rtol=1e-3, atol=1e-4)
     assert np.abs(g("q") - st["q"]).max() < 1e-5 and np.abs(g("v") - st["v"]).max() < 1e-5
     w, w0 = wrench(g("f"), wc.params), wrench(st["f"], wc.params)
-    fz = np.maximum(np.abs(w0[:, :, 2:3]), 1.0)
-    assert (np.abs(w - w0) <= 1e-4 * fz + 1e-3 * np.abs(w0)).all()
-    tau_ok = (np.abs(g("tau") - st["tau"]) <= 1e-4 + 1e-3 * np.abs(st["tau"])).all(axis=1)
-    assert tau_ok.mean() >= 0.98 and np.allclose(g("tau"), st["tau"], rtol=1e-3, atol=1e-3)
+    assert np.allclose(w, w0, rtol=1e-3, atol=1e-4)
+    assert np.allclose(g("tau"), st["tau"], rtol=1e-3, atol=1e-4)
     same = (wc.con_pairs.cpu().numpy() == st["con_geom"]).all(axis=1)
     assert same.mean() >= 0.85 and (wc.ncon.cpu().numpy() == st["ncon"]).mean() >= 0.95
     dq, dqv = np.abs(g("qpos") - st["qpos"])[same], np.abs(g("qvel") - st["qvel"])[same]
