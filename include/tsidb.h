@@ -78,8 +78,11 @@ int tsidb_set_refs(tsidb_handle h, const void *com_ref, const void *posture_ref,
  * TSIDB_OPT_LDS_PAD (diagnostic): bytes of unused dynamic LDS added to every k_tick / k_sim workgroup (0 .. 40960) - lowers the
  * number of resident workgroups per CU, for occupancy measurements; default 0.
  * TSIDB_OPT_CU_SPLIT: whether tsidb_stream_create hands out streams on disjoint halves of the CUs: 1 always, 0 never, -1 (default)
- * for up to 512 envs. */
-enum { TSIDB_OPT_SIM_WAVES = 1, TSIDB_OPT_LDS_PAD = 2, TSIDB_OPT_CU_SPLIT = 3 };
+ * for up to 512 envs.
+ * TSIDB_OPT_SIM_PACK: 1 = the sim kernel runs TWO envs per wavefront (32 lanes each; tsidb_sim2.hpp) where one step per launch
+ * is issued (tsidb_sim, tsidb_step, tsidb_sim_batch with one snapshot); per env bit-identical to the one-env kernel.  Only for
+ * robots whose bodies, dofs, geoms and contacts fit 32 lanes (the v1 robot); the library of another robot rejects the option. */
+enum { TSIDB_OPT_SIM_WAVES = 1, TSIDB_OPT_LDS_PAD = 2, TSIDB_OPT_CU_SPLIT = 3, TSIDB_OPT_SIM_PACK = 4 };
 int tsidb_set_option(tsidb_handle h, int option, int value);
 int tsidb_get_option(tsidb_handle h, int option, int *value); /* the EFFECTIVE setting (TSIDB_OPT_CU_SPLIT: 1 if tsidb_stream_create
                                                                 * masks its streams for this handle's batch size) */
@@ -140,9 +143,11 @@ int tsidb_sim(tsidb_handle h, const void *q_tsid, const void *v_tsid, void *qpos
 /* n_steps (1 .. TSIDB_MAX_SIM_BATCH) consecutive sim steps in ONE launch: step b teleports to / takes its joint targets from
  * slot slots[b] (host array, 0 .. 15) of the snapshot rings q_ring [K,N,27], v_ring [K,N,26] (v_ring may be NULL) - what n_steps
  * calls of tsidb_sim with q_tsid = q_ring[slots[b]] do, without the launch gaps between them (the pipelined open-loop step
- * hands over the TSID states of several ticks at once; envs do not interact, so each steps on its own).  float64: bit for bit
- * (tested over 1400 walking steps); float32: to rounding - the single- and the multi-step kernel are separate compilations of
- * one source and fuse one multiply-add differently (first 1-ulp difference after 231 walking steps, tools/dbg_batch_f32.py).
+ * hands over the TSID states of several ticks at once; envs do not interact, so each steps on its own).  Bit for bit, in
+ * float64 and float32: the library is built with -ffp-contract=on, so the separately compiled instantiations of the sim kernel
+ * (single- / multi-step, one / two wavefronts per env, two envs per wavefront) fuse exactly the multiply-adds the source writes
+ * as one expression (with hipcc's default, fast, the multi-step kernel differed from the single-step one by 1 ulp in float32
+ * after 231 walking steps; tests: test_shard_invariance_across_kernel_shapes).
  * ncon / con_pairs / info are the last step's. */
 enum { TSIDB_MAX_SIM_BATCH = 8 };
 int tsidb_sim_batch(tsidb_handle h, int n_steps, const void *q_ring, const void *v_ring, const int32_t *slots, void *qpos, void *qvel,

@@ -477,6 +477,40 @@ def test_shard_invariance_bitwise():
         assert torch.equal(getattr(full, name), torch.cat([getattr(a, name), getattr(b, name)])), name
 
 
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_shard_invariance_across_kernel_shapes(dtype):
+    """a strong split of one batch over 1 / 2 / 8 GPUs crosses the thresholds at which the library changes the
+    shape of the sim kernel - one step per launch above 1024 envs, eight per launch (a separately compiled instantiation) up
+    to 1024, two wavefronts per env up to 384 - all with the DEFAULT options and the pipelined step the bench uses.  Walkers
+    (start phase, lift-off, a touch-down: 800 ticks) on one controller of 2048 envs against 2 x 1024 and against the first and
+    the last of 8 x 256: bit-identical, in float32 as well (the library is built with -ffp-contract=on: every instantiation
+    rounds alike by construction)."""
+    n, dt, ticks = 2048, 0.002, 800
+    g = torch.Generator(device="cpu").manual_seed(17)
+    scale = 0.5 + 0.47 * torch.rand(n, generator=g, dtype=torch.float64)
+    def run(lo, hi):
+        wc = make(hi - lo, dtype, walking=True, reference_quirks=False)
+        from tsid_control_amd.walk_planner import WalkSchedule, op3_walking_posture
+        wc.set_posture_bias(op3_walking_posture())
+        sched = WalkSchedule.on_device(wc, scale=scale[lo:hi])
+        for i in range(ticks):
+            wc.step_pipelined(walk=(sched, i * dt))
+        wc.sync_sim()
+        torch.cuda.synchronize()
+        return wc
+    full = run(0, n)
+    import ctypes as C
+    opt = lambda w, o: (lambda v: (w._L.tsidb_get_option(w._h, o, C.byref(v)), v.value)[1])(C.c_int(0))
+    assert opt(full, 1) == 1 and full.sim_batch == 1
+    assert int(full.status.abs().sum()) == 0 and int((full.contact_active.sum(dim=1) == 1).sum()) > n // 2   # walking, single support
+    for lo, hi in ((0, 1024), (1024, 2048), (0, 256), (1792, 2048)):
+        part = run(lo, hi)
+        assert part.sim_batch == 8 and opt(part, 1) == (2 if hi - lo <= 384 else 1)
+        for k in ("q", "v", "tau", "dv", "f", "status", "rows", "qpos", "qvel", "qacc_warmstart", "ncon", "con_pairs", "contact_active"):
+            assert torch.equal(getattr(full, k)[lo:hi], getattr(part, k)), (dtype, lo, hi, k)
+        del part
+
+
 def test_full_size_properties():
     """BASELINE config sizes: 4096 envs (one GPU) - size-independent properties instead of the oracle."""
     wc = make(4096)
@@ -1447,6 +1481,31 @@ def test_two_wavefront_sim_is_bit_identical():
     for k in ("q", "v", "tau", "qpos", "qvel", "qacc_warmstart", "ncon", "con_pairs", "info", "rows"):
         assert torch.equal(getattr(a, k), getattr(b, k)), k
     assert int(a.ncon.max()) > 4 and int((a.con_pairs & 0x8000).bool().sum()) > 0     # floor and robot<->robot contacts were there
+
+
+@pytest.mark.parametrize("dtype,n", [("f64", 96), ("f64", 33), ("f32", 64)])
+def test_packed_sim_is_bit_identical(dtype, n):
+    """conf.sim_pack: the sim kernel with TWO envs per wavefront (tsidb_sim2.hpp: 32 lanes per env, DPP broadcasts instead of
+    v_readlane, per-env divergent control flow) against one env per wavefront - same operations on the same data in the same
+    order, bit for bit: perturbed standing, randomised floors with terrain steps, self-colliding poses (MPR, dense Newton
+    factor), an odd number of envs (the last wavefront holds one env), envs paired with a diverged neighbour"""
+    a, b = make(n, dtype, sim_waves=1, sim_pack=0), make(n, dtype, sim_waves=1, sim_pack=1)
+    for w in (a, b):
+        perturb(w, 41, dq=0.04, dv=0.05)
+        w.randomize(seed=3)
+        w.qpos[: n // 3, 7:] = _self_collision_poses(n // 3, 5).to(w.device, w.dtype)
+        w.qvel[n - 2, :] = 1e9     # a diverged env (its step is skipped, failure bit 4) beside a healthy one
+    for i in range(30):
+        a.step()
+        b.step()
+    for i in range(20):
+        a.sim_step(teleport=False)
+        b.sim_step(teleport=False)
+    torch.cuda.synchronize()
+    for k in ("q", "v", "tau", "qpos", "qvel", "qacc_warmstart", "ncon", "con_pairs", "info", "rows"):
+        assert torch.equal(getattr(a, k), getattr(b, k)), (k, (getattr(a, k) != getattr(b, k)).nonzero()[:8].tolist())
+    assert int(a.ncon.max()) > 4 and int((a.con_pairs & 0x8000).bool().sum()) > 0     # floor and robot<->robot contacts were there
+    assert int(a.info[n - 2, 3]) == 4 and int(a.info[n - 1, 3]) != 4
 
 
 def test_fused_walk_tick_and_device_episodes_in_the_pipelined_loop():

@@ -5,7 +5,7 @@ Compiles csrc/tsidb_api.hip to a throw-away object (the product .so is not touch
 import re, subprocess, sys, tempfile
 from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
-flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mllvm", "-disable-machine-licm", *sys.argv[1:]]
+flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mllvm", "-disable-machine-licm", "-ffp-contract=on", *sys.argv[1:]]
 with tempfile.TemporaryDirectory() as td:
     r = subprocess.run(["/opt/rocm/bin/hipcc", *flags, "-c", "-Rpass-analysis=kernel-resource-usage", "-o", f"{td}/x.o",
                         str(ROOT / "tsid_control_amd/csrc/tsidb_api.hip")], capture_output=True, text=True)

@@ -2,6 +2,7 @@
 #include "../../include/tsidb.h"
 #include "tsidb_common.hpp"
 #include "tsidb_sim.hpp"
+#include "tsidb_sim2.hpp"
 #include "tsidb_tick.hpp"
 
 #include <cmath>
@@ -265,6 +266,45 @@ __global__ __launch_bounds__(WAVE * NW) __attribute__((amdgpu_waves_per_eu(TSIDB
                           qacc ? qacc + E * NV : nullptr, ncon ? ncon + e : nullptr, con ? con + E * MAXCON : nullptr,
                           info ? info + E * 4 : nullptr);
     if constexpr (MULTI) __syncthreads(); // both wavefronts; the step's state is written before the next step reads it
+  }
+}
+
+// Two envs per wavefront (tsidb_sim2.hpp; TSIDB_OPT_SIM_PACK): env 2 p + h on lanes [32 h, 32 h + 32) of workgroup p's one
+// wavefront, each half with its own SimLds (2 x 20 KB: four workgroups = eight envs per CU, one wavefront per SIMD with the
+// whole register file).  One step per launch.  Per env bit-identical to k_sim<T, 1, false>.
+template <typename T>
+__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_sim2(const DevModel<T> *__restrict__ mp, int n, SimRing<T> ring, T *qpos, T *qvel,
+                                              T *qacc_ws, const T *env_params, const T *terrain, const T *motor_tau, T *qacc, int *ncon,
+                                              int *con, int *info) {
+  if constexpr (SIM_PACKABLE) {
+    __shared__ SimLds<T> Ls[2];
+    const int lane = threadIdx.x, hf = lane >> 5, hl = lane & (pk::LPE - 1);
+    const int npair = (n + 1) / 2;
+    if ((int)blockIdx.x >= npair) return;
+    const int e2 = 2 * env_of_block(blockIdx.x, npair) + hf;
+    const bool live = e2 < n; // (odd n: the last wavefront's second half has no env - it reads env n - 1 and writes nothing)
+    const int e = live ? e2 : n - 1;
+    const size_t E = (size_t)e;
+    const size_t slot = (size_t)(ring.slots & 15ull);
+    const T *q_tsid = ring.q ? ring.q + slot * (size_t)n * NQ : nullptr, *v_tsid = ring.v ? ring.v + slot * (size_t)n * NV : nullptr;
+    T chk = 0, big = 0;
+    if (hl < NQ) { big += fabs(qpos[E * NQ + hl]); chk += q_tsid ? fabs(q_tsid[E * NQ + hl]) : T(0); }
+    if (hl < NV) { big += fabs(qvel[E * NV + hl]); chk += fabs(qacc_ws[E * NV + hl]) + (v_tsid ? fabs(v_tsid[E * NV + hl]) : T(0)); }
+    if (hl < NA && motor_tau) chk += fabs(motor_tau[E * NA + hl]);
+    big = pk::sum(big);
+    const bool skip = pk::ballot(!(chk <= Eps<T>::inf), lane) != 0u || !(big <= T(SIM_STATE_BOUND));
+    if (!live) return;
+    if (skip) {
+      if (hl == 0) {
+        if (info) { info[E * 4 + 2] = 0; info[E * 4 + 3] = 4; }
+        if (ncon) ncon[e] = 0;
+      }
+      if (con && hl < MAXCON) con[E * MAXCON + hl] = -1;
+      return;
+    }
+    sim_step_pair<T>(*mp, Ls[hf], lane, q_tsid ? q_tsid + E * NQ : nullptr, v_tsid ? v_tsid + E * NV : nullptr, qpos + E * NQ, qvel + E * NV, qacc_ws + E * NV,
+                     env_params ? env_params + E * 8 : nullptr, terrain ? terrain + E * 20 : nullptr, motor_tau ? motor_tau + E * NA : nullptr,
+                     qacc ? qacc + E * NV : nullptr, ncon ? ncon + e : nullptr, con ? con + E * MAXCON : nullptr, info ? info + E * 4 : nullptr);
   }
 }
 
@@ -637,6 +677,7 @@ static void chain_table(const int *parent, int n, int (*chain)[8]) {
 struct tsidb_ctx {
   int device = 0, dtype = 0, num_envs = 0;
   int sim_waves = 1; // wavefronts per env in k_sim (tsidb_set_option)
+  int sim_pack = 0;  // two envs per wavefront in the sim kernel (k_sim2; one step per launch, robots that fit 32 lanes)
   unsigned lds_pad = 0; // diagnostic: unused dynamic LDS per workgroup of k_tick / k_sim (occupancy experiments)
   int cu_split = -1;    // tsidb_stream_create: tick and sim streams on disjoint halves of the CUs (-1 = up to 512 envs)
   Blob blob;
@@ -944,7 +985,10 @@ static void launch_sim(tsidb_ctx *h, int B, const void *q_ring, const void *v_ri
     hipLaunchKernelGGL((k_sim<T, NW, MULTI>), dim3(h->num_envs), dim3(WAVE * NW), h->lds_pad, s, (const DevModel<T> *)h->d_model, h->num_envs, B, ring, \
                        (T *)qpos, (T *)qvel, (T *)qacc_ws, (const T *)h->env_params, (const T *)h->terrain, (const T *)motor_tau,     \
                        (T *)qacc, ncon, con, info)
-    if (B > 1) { if (h->sim_waves == 2) TSIDB_LAUNCH_SIM(2, true); else TSIDB_LAUNCH_SIM(1, true); }
+    if (B == 1 && h->sim_pack && SIM_PACKABLE)
+      hipLaunchKernelGGL((k_sim2<T>), dim3((h->num_envs + 1) / 2), dim3(WAVE), 0, s, (const DevModel<T> *)h->d_model, h->num_envs, ring, (T *)qpos, (T *)qvel,
+                         (T *)qacc_ws, (const T *)h->env_params, (const T *)h->terrain, (const T *)motor_tau, (T *)qacc, ncon, con, info);
+    else if (B > 1) { if (h->sim_waves == 2) TSIDB_LAUNCH_SIM(2, true); else TSIDB_LAUNCH_SIM(1, true); }
     else { if (h->sim_waves == 2) TSIDB_LAUNCH_SIM(2, false); else TSIDB_LAUNCH_SIM(1, false); }
 #undef TSIDB_LAUNCH_SIM
   }
@@ -1074,6 +1118,7 @@ int tsidb_set_option(tsidb_handle h, int option, int value) {
   if (!h) return -1;
   if (option == TSIDB_OPT_SIM_WAVES && (value == 1 || value == 2)) { h->sim_waves = value; return 0; }
   if (option == TSIDB_OPT_LDS_PAD && value >= 0 && value <= 40960) { h->lds_pad = (unsigned)value; return 0; }
+  if (option == TSIDB_OPT_SIM_PACK && (value == 0 || (value == 1 && SIM_PACKABLE))) { h->sim_pack = value; return 0; }
   if (option == TSIDB_OPT_CU_SPLIT && value >= -1 && value <= 1) { h->cu_split = value; return 0; }
   h->err = "tsidb_set_option: unknown option or value";
   return 1;
@@ -1084,6 +1129,7 @@ int tsidb_get_option(tsidb_handle h, int option, int *value) {
   if (!value) { h->err = "tsidb_get_option: null value"; return 1; }
   if (option == TSIDB_OPT_SIM_WAVES) { *value = h->sim_waves; return 0; }
   if (option == TSIDB_OPT_LDS_PAD) { *value = (int)h->lds_pad; return 0; }
+  if (option == TSIDB_OPT_SIM_PACK) { *value = h->sim_pack; return 0; }
   if (option == TSIDB_OPT_CU_SPLIT) { *value = (h->cu_split == 1 || (h->cu_split < 0 && h->num_envs <= 512)) ? 1 : 0; return 0; }
   h->err = "tsidb_get_option: unknown option";
   return 1;

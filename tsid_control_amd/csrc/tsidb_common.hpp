@@ -387,7 +387,8 @@ __device__ __forceinline__ void wave_sync() {
 #define TSIDB_SYNC1() __syncthreads()
 #endif
 template <int NW> __device__ __forceinline__ void wg_sync() { // every wavefront of the workgroup
-  if constexpr (NW == 1) TSIDB_SYNC1();
+  if constexpr (NW == 0) wave_sync(); // (NW = 0: the packed kernels - one wavefront, two envs, hand-overs inside divergent code)
+  else if constexpr (NW == 1) TSIDB_SYNC1();
   else __syncthreads();
 }
 

@@ -600,7 +600,10 @@ template <typename T> __device__ __forceinline__ T origin_tri_closest(const T *a
 // (geom1 -> geom2) and pos.
 // a, b: geom indices; their hulls are placed by the bodies that carry them.  margin > 0 (robot/v0/robot.xml:4): each
 // hull is inflated by margin / 2 along the support direction (as mjc_Convex does), the caller takes dist = margin - depth.
-template <typename T>
+template <typename T, bool TERR> // (the packed kernels' support search, tsidb_sim2.hpp)
+__device__ __forceinline__ int hull_argmin_p(const DevModel<T> &m, int lane, int b, T r6, T r7, T r8, T pz, T tie, const T *terr,
+                                             const T *Rw, T px, T py, T hmax_all, T &zmin_out);
+template <typename T, bool PACK = false>
 __device__ __forceinline__ bool mpr_penetration(const DevModel<T> &m, const SimLds<T> &L, int lane, int a, int b, T margin, T &depth, T *dir_out, T *pos) {
   const T TOL = sizeof(T) == 8 ? T(1e-10) : T(2e-6), TIE = sizeof(T) == 8 ? T(1e-12) : T(1e-7);
   const T TINY2 = sizeof(T) == 8 ? T(1e-30) : T(1e-20), SIDE = sizeof(T) == 8 ? T(1e-14) : T(1e-9);
@@ -617,8 +620,13 @@ __device__ __forceinline__ bool mpr_penetration(const DevModel<T> &m, const SimL
     T ra[3], rb[3], zz, wa[3], wb[3];
     mat3Tvec(Ra, d, ra);
     mat3Tvec(Rb, d, rb);
+    if constexpr (PACK) {
+      ia = hull_argmin_p<T, false>(m, lane, a, -ra[0], -ra[1], -ra[2], T(0), TIE, nullptr, nullptr, T(0), T(0), T(0), zz);
+      ib = hull_argmin_p<T, false>(m, lane, b, rb[0], rb[1], rb[2], T(0), TIE, nullptr, nullptr, T(0), T(0), T(0), zz);
+    } else {
     ia = hull_argmin<T, false>(m, lane, a, -ra[0], -ra[1], -ra[2], T(0), TIE, nullptr, nullptr, T(0), T(0), T(0), zz);
     ib = hull_argmin<T, false>(m, lane, b, rb[0], rb[1], rb[2], T(0), TIE, nullptr, nullptr, T(0), T(0), T(0), zz);
+    }
     wvert(Ra, pa, ia, wa);
     wvert(Rb, pb, ib, wb);
     v[0] = wa[0] - wb[0]; v[1] = wa[1] - wb[1]; v[2] = wa[2] - wb[2];

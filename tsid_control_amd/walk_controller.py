@@ -89,6 +89,11 @@ class WalkController:
         sw = int(getattr(conf, "sim_waves", 0))   # 0 = the library's choice (2 wavefronts per env up to 384 envs, else 1)
         if sw:
             _lib.check(L, self._h, L.tsidb_set_option(self._h, 1, sw), "tsidb_set_option(sim_waves)")
+        sp = int(getattr(conf, "sim_pack", -1))   # -1 = the library's choice; 1 = two envs per wavefront in the sim kernel (tsidb_sim2.hpp)
+        if os.environ.get("TSIDB_SIM_PACK"):      # diagnostic override (A/B runs of bench.py)
+            sp = int(os.environ["TSIDB_SIM_PACK"])
+        if sp >= 0:
+            _lib.check(L, self._h, L.tsidb_set_option(self._h, 4, sp), "tsidb_set_option(sim_pack)")
         if os.environ.get("TSIDB_LDS_PAD"):       # diagnostic (occupancy measurements): unused LDS per workgroup
             _lib.check(L, self._h, L.tsidb_set_option(self._h, 2, int(os.environ["TSIDB_LDS_PAD"])), "tsidb_set_option(lds_pad)")
         self.cop_ref = z(N, 3)   # reference of the CoP force task (legacy/biped.py:79-80; conf.w_cop)
