@@ -85,7 +85,7 @@ def parse():
                          "available inside a graph")
     ap.add_argument("--sim-batch", type=int, default=0,
                     help="conf.pipeline_sim_batch: sim stages handed to the second stream this many at a time, in one launch "
-                         "(0 = the library's default: 4 up to 1024 envs, else 1)")
+                         "(0 = the default: 8 up to 1024 envs, else 1 - WalkController.sim_batch)")
     ap.add_argument("--device-plan", action="store_true",
                     help="walk workload: the episode plans are BUILT ON THE DEVICE (tsidb_walk_plan / k_plan: footsteps, swing "
                          "polynomials, DCM / LIPM CoM plan per env, path scales U(0.5, 1) drawn per env) and the episode lifecycle "
@@ -432,8 +432,9 @@ def secondary_runs(a, dev):
         # torque bounds at 1.2 N m (the gait needs up to 2.3 N m) with the envs spread over one step period: at any
         # tick a good part of the batch is in the dual active-set loop (frac_envs_in_active_set_loop_window_mean)
         ("cfg3_walk_4096_tight_torque_bounds", dict(workload="walk", tau_max_scaling=0.12, dephase=0.5, preroll=800), 4096),
-        # the per-GPU share of the 4096 walkers at 8 GPUs (strong split): a step is one wavefront's latency (k_sim's);
-        # capturing the steps in a HIP graph (one launch per 16 steps) does not help - the host is not the bound
+        # the per-GPU share of the 4096 walkers at 8 GPUs (strong split): a step is one wavefront's latency.  (Replaying the
+        # steps from a HIP graph - WalkController.capture_steps, a convenience API for callers that want one launch per K
+        # steps - is slower than this eager pipeline, DESIGN.md section 5 "Streams", and is no longer benched: --graph K.)
         ("cfg3_walk_4096_closed_loop", dict(workload="walk", closed_loop=True, steps=max(a.secondary_steps, 400), preroll=600), 4096),
         ("cfg3_walk_512_eager", dict(workload="walk", steps=800), 512),
         # the per-GPU shares of the 4096 walkers at 4 and 2 GPUs (strong split)
@@ -443,8 +444,6 @@ def secondary_runs(a, dev):
         ("cfg5_65536_randomized", dict(workload="walk", randomize=True, steps=max(a.secondary_steps // 2, 100), event_every=8), 65536),
         # the reference's second robot (robot/v0: 52 collision meshes, condim 4, joint damping), perturbed standing
         ("v0_stand_4096", dict(workload="stand", robot="v0", steps=max(a.secondary_steps, 200), warmup=100), 4096),
-        # (last: streams created after a HIP graph has run in the process may share a hardware queue)
-        ("cfg3_walk_512_graph16", dict(workload="walk", steps=800, graph=16), 512),
     ]
     wsz = 8 if a.dtype == "f64" else 4
     for name, over, n in cases:

@@ -215,7 +215,11 @@ int tsidb_set_posture_bias(tsidb_handle h, const void *posture_bias);
  * into the robot's heading and started between its feet.  Outputs: steps [N,K+2,4] float64 = x, y, yaw, side of every
  * footstep (the two initial ones first); nsteps [N]; coef, side, rest, com as tsidb_walk_update reads them; flags [N] (may
  * be NULL) bit 0 = the plan needed more than K steps and was cut, bit 1 = the path had no direction (fewer than two distinct
- * vertices; npts[e] is clamped to P): no step planned, the env stands.  The env's clock restarts: t_offset [N] (may be NULL)
+ * vertices; npts[e] is clamped to P): no step planned, the env stands; bit 2 = a path piece longer than 4096 resample intervals
+ * (or with a non-finite vertex) was resampled coarser; bit 3 (with bit 1) = the CoM is not above the feet after the descent
+ * (com_ref[2] - com_drop <= 1 mm: plan before a reset, or com_drop >= the standing height): no step planned, finite tables.
+ * Rejected by the call (error): non-finite parameters, step_width <= 0, resample_ds in (0, step_length / 1000), a unicycle
+ * path of more than 65536 vertices or with dt <= 0, a scale range that is not 0 < lo <= hi.  The env's clock restarts: t_offset [N] (may be NULL)
  * receives `t` (or *t_device, float64 device), td_latch [N] (may be NULL) -1. */
 enum { TSIDB_PLAN_NPARAMS = 16 };
 int tsidb_walk_plan(tsidb_handle h, const int32_t *env_ids, int n_ids, const void *done_rows, int rows_ld,

@@ -1488,6 +1488,26 @@ def test_plan_kernel_matches_restatement_and_reference_footsteps(oracle, dtype):
         assert torch.isfinite(getattr(sched, k)[:3]).all() and diff(getattr(sched, k)[:3], twin[k]) < (tol if k != "steps" else 1e-7), k
 
 
+def test_plan_kernel_guards_its_loops_and_tables():
+    """tsidb_walk_plan runs one thread per env over parameter-sized loops - parameters that would stall the GPU
+    or put NaN into the tables are rejected by the call or flagged per env: a resample step of step_length / 1e6, a
+    unicycle path of 1e9 vertices, non-finite parameters (errors); com_drop above the standing CoM height (flag bits 1 and
+    3: no step planned, every table finite, the env keeps standing through 50 ticks)."""
+    from tsid_control_amd import _lib
+    from tsid_control_amd.walk_planner import WalkSchedule
+    n = 8
+    wc, sched = _walker(n, plan=False)
+    for bad in (dict(resample_ds=wc.conf.step_length * 1e-6), dict(unicycle=(0.5, 0.1, 0.1, 1e9)), dict(unicycle=(0.5, 0.1, 0.0, 100)),
+                dict(com_drop=float("nan")), dict(scale_range=(0.0, 1.0))):
+        with pytest.raises(_lib.TsidbError):
+            WalkSchedule.on_device(wc, **bad)
+    sched = WalkSchedule.on_device(wc, com_drop=1.0)
+    torch.cuda.synchronize()
+    assert sched.flags.tolist() == [10] * n and int(sched.nsteps.abs().sum()) == 0
+    for t in (sched.coef, sched.rest, sched.com, sched.steps):
+        assert bool(torch.isfinite(t).all())
+
+
 def test_episode_lifecycle_on_the_device():
     """64 walkers; some are made to fall at chosen ticks (base pushed below done_base_height): the tick reports done,
     reset_done() resets exactly those envs and replans them with a NEW path on the device (no host sync), and each then walks
@@ -1602,7 +1622,7 @@ def test_contact_caps_are_flagged(oracle):
 
 def test_two_wavefront_sim_is_bit_identical():
     """conf.sim_waves: the small-batch shape of the sim kernel (collision phase on a second wavefront beside the
-    unconstrained dynamics; the default up to 2048 envs) against one wavefront per env - same operations on the same data,
+    unconstrained dynamics; the library's default up to 384 envs, tsidb_create) against one wavefront per env - same operations on the same data,
     bit for bit: perturbed standing, randomised floors with terrain steps, self-colliding poses"""
     n = 96
     a, b = make(n, sim_waves=1), make(n, sim_waves=2)

@@ -15,6 +15,9 @@ WALK = len(sys.argv) > 3 and sys.argv[3] == "walk"
 if WALK:
     from tsid_control_amd.walk_planner import op3_walking_conf, op3_walking_posture
     op3_walking_conf(conf); conf.reference_quirks = False
+import os
+if os.environ.get("TSIDB_TAU_MAX_SCALING"):    # (bench.py --tau-max-scaling: torque bounds tight enough to be active)
+    conf.tau_max_scaling = float(os.environ["TSIDB_TAU_MAX_SCALING"])
 wc = WalkController(conf, num_envs=N)
 torch.manual_seed(0)
 if len(sys.argv) > 3 and sys.argv[3] == "walk":
@@ -22,6 +25,8 @@ if len(sys.argv) > 3 and sys.argv[3] == "walk":
     lf, rf = wc.frames[0, 0, 9:11].cpu().numpy(), wc.frames[0, 1, 9:11].cpu().numpy()
     wc.posture_ref += torch.as_tensor(op3_walking_posture(), device=wc.device).to(wc.dtype)
     sched = WalkSchedule.from_demo_paths(N, conf, wc.device, wc.dtype, seed=1, q0_feet=(lf, rf), com0=wc.com_ref[0, :3].double().cpu().numpy())
+    if os.environ.get("TSIDB_DEPHASE"):        # (bench.py --dephase: per-env start delays)
+        sched.set_phase_offsets(torch.rand(N, generator=torch.Generator().manual_seed(7), dtype=torch.float64) * float(os.environ["TSIDB_DEPHASE"]))
     for i in range(int(sys.argv[4]) if len(sys.argv) > 4 else 100):
         sched.apply(wc, i * conf.dt); wc.step()
 else:
@@ -45,6 +50,14 @@ for nm, ix in zip(names_t, idx_t):
     d = np.median(b[:, ix[1]] - b[:, ix[0]])
     print(f"  {nm:24s} {d:10.0f} cyc  {100*d/tot:5.1f}%")
 print(f"  {'total':24s} {tot:10.0f} cyc")
+bb = np.arange(n)                      # stamp row = workgroup; its env = env_of_block (tsidb_common.hpp: XCD x owns a contiguous env range)
+env_of_block = (bb % 8) * (N // 8) + np.minimum(bb % 8, N % 8) + bb // 8
+it = wc.info[:, 0].cpu().numpy()[env_of_block]
+tt = b[:, 9] - b[:, 0]
+for lo_, hi_ in ((1, 1), (2, 3), (4, 7), (8, 15), (16, 999)):
+    sel = (it >= lo_) & (it <= hi_)
+    if sel.any():
+        print(f"  envs with {lo_}-{hi_} qp iterations: {int(sel.sum()):5d}  median total {np.median(tt[sel]):9.0f} cyc  inequality loop {np.median((b[:, 8] - b[:, 6])[sel]):9.0f}")
 for nm, k in (("  as: sweep (row values)", 10), ("  as: select+np", 11), ("  as: d = J^T np", 12), ("  as: householder+z", 13), ("  as: r, steps, add", 14)):
     print(f"{nm:26s} {np.median(b[:, k]):10.0f} cyc (sum over iterations)")
 for nm, k in (("  rbd: setup+sincos", 15), ("  rbd: depth loop", 23), ("  rbd: inertia+force", 29), ("  rbd: subtree gather", 30), ("  rbd: per-dof h,M", 31)):

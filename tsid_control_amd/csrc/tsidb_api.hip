@@ -474,7 +474,8 @@ __global__ __launch_bounds__(64) void k_plan(int n, const int *env_ids, int n_id
     }
     if (i == 0) { prev[0] = a[0] = b[0]; prev[1] = a[1] = b[1]; continue; }
     const double seg = sqrt((b[0] - a[0]) * (b[0] - a[0]) + (b[1] - a[1]) * (b[1] - a[1]));
-    int mres = ds > 0 ? (int)ceil(seg / ds) : 1;
+    int mres = ds > 0 && seg / ds < 4096.0 ? (int)ceil(seg / ds) : (ds > 0 ? 4096 : 1);
+    if (ds > 0 && !(seg / ds < 4096.0)) cut |= 4; // a piece of more than 4096 resample intervals (or a non-finite vertex): resampled coarser, flag bit 4
     if (mres < 1) mres = 1;
     for (int j = 1; j <= mres; j++) {
       const double qf = (double)j / mres, p[2] = {a[0] + (b[0] - a[0]) * qf, a[1] + (b[1] - a[1]) * qf};
@@ -488,7 +489,11 @@ __global__ __launch_bounds__(64) void k_plan(int n, const int *env_ids, int n_id
   }
   // a path without a direction (fewer than two distinct vertices; the reference's planner raises on it) plans no step: the env
   // stands, flag bit 1
-  const bool degenerate = !(dx != 0 || dy != 0);
+  // the LIPM needs a positive CoM height above the feet after the descent (plan() before a reset, or com_drop >= that height,
+  // would put NaN into every table): such an env plans no step and stands, flag bit 8
+  const bool no_height = !(com0[2] - pp[6] > 1e-3);
+  const bool degenerate = !(dx != 0 || dy != 0) || no_height;
+  if (no_height) nst = 2;
   if (!degenerate) {
     sd = !sd;
     add_step(dx, dy, sd, prev);
@@ -496,7 +501,7 @@ __global__ __launch_bounds__(64) void k_plan(int n, const int *env_ids, int n_id
   }
   const int ns = nst - 2;
   nsteps[e] = ns;
-  if (flags) flags[e] = cut | (degenerate ? 2 : 0);
+  if (flags) flags[e] = cut | (degenerate ? 2 : 0) | (no_height ? 8 : 0);
   for (int k = nst; k < K + 2; k++) st[4 * k] = st[4 * k + 1] = st[4 * k + 2] = st[4 * k + 3] = 0;
   // swing polynomials and rest placements; yaw relative to the initial heading
   double cur[2][4];
@@ -533,7 +538,7 @@ __global__ __launch_bounds__(64) void k_plan(int n, const int *env_ids, int n_id
     side[E * K + k] = sw;
   }
   // CoM plan: DCM end points backwards (kept in the table's d slot), then forwards one LIPM segment per phase
-  const double w = sqrt(9.80665 / (com0[2] - pp[6])), ewT = exp(-w * Tst);
+  const double w = sqrt(9.80665 / (no_height ? 1e-3 : com0[2] - pp[6])), ewT = exp(-w * Tst);
   T *cm = com + E * (K + 2) * 6;
   double fin[2] = {com0[0], com0[1]}, xi[2];
   if (ns > 0) { fin[0] = 0.5 * (st[4 * ns] + st[4 * (ns + 1)]); fin[1] = 0.5 * (st[4 * ns + 1] + st[4 * (ns + 1) + 1]); }
@@ -677,6 +682,11 @@ static void chain_table(const int *parent, int n, int (*chain)[8]) {
 struct tsidb_ctx {
   int device = 0, dtype = 0, num_envs = 0;
   int sim_waves = 1; // wavefronts per env in k_sim (tsidb_set_option)
+  std::vector<hipStream_t> used_streams; // streams this handle has launched model-reading kernels on (tsidb_set_params waits for them)
+  void note_stream(hipStream_t s) {
+    for (hipStream_t x : used_streams) if (x == s) return;
+    if (used_streams.size() < 32) used_streams.push_back(s);
+  }
   int sim_pack = 0;  // two envs per wavefront in the sim kernel (k_sim2; one step per launch, robots that fit 32 lanes)
   unsigned lds_pad = 0; // diagnostic: unused dynamic LDS per workgroup of k_tick / k_sim (occupancy experiments)
   int cu_split = -1;    // tsidb_stream_create: tick and sim streams on disjoint halves of the CUs (-1 = up to 512 envs)
@@ -950,6 +960,7 @@ static void launch_tick(tsidb_ctx *h, void *q, void *v, void *tau, void *dv, voi
                         void *frames, int32_t *info, hipStream_t s, const void *qpos_sim = nullptr,
                         const void *qvel_sim = nullptr, const WalkArgs<T> *walk = nullptr, void *q_snap = nullptr, void *v_snap = nullptr) {
   if (obs && obs_ld < NOBS) throw std::string("obs row stride must be at least TSIDB_NOBS");
+  h->note_stream(s);
   WalkArgs<T> wa;
   memset(&wa, 0, sizeof wa);
   if (walk) wa = *walk;
@@ -970,6 +981,7 @@ static void launch_sim(tsidb_ctx *h, int B, const void *q_ring, const void *v_ri
   if constexpr (!TOPO_HAS_SIM) throw std::string("this library was built without the sim stage");
   else {
     if (B < 1 || B > TSIDB_MAX_SIM_BATCH) throw std::string("sim batch must be 1 .. TSIDB_MAX_SIM_BATCH steps");
+    h->note_stream(s);
     SimRing<T> ring;
     ring.q = (const T *)q_ring; ring.v = (const T *)v_ring; ring.slots = 0;
     for (int b = 0; b < B; b++) {
@@ -977,10 +989,14 @@ static void launch_sim(tsidb_ctx *h, int B, const void *q_ring, const void *v_ri
       if (sl < 0 || sl > 15) throw std::string("sim batch: slot numbers must be 0 .. 15");
       ring.slots |= (unsigned long long)sl << (4 * b);
     }
-    // while every wavefront of the step is resident at once (1024 SIMDs x 2; the tick kernel of the next step runs beside
-    // the sim: 3 N <= 2048) a step costs one wavefront's latency: two wavefronts per env there (collision beside the
-    // unconstrained dynamics), bit-identical results.  Measured: 512 envs sim 0.083 -> 0.077 ms; at 1024 and 2048 envs the
-    // extra wavefronts queue behind the others and nothing is gained
+    // Two wavefronts per env (collision beside the unconstrained dynamics, bit-identical) shorten the step only while every
+    // wavefront has a SIMD to itself: 2 N sim wavefronts + N of the tick running beside them on 1024 SIMDs, or 2 N on the
+    // 512 SIMDs of the sim stream's half when the streams are CU-split (<= 512 envs) - the library picks NW = 2 up to 384
+    // envs (tsidb_create; k_sim at 128 / 256 / 384 envs 5-9 % shorter).  Beyond that it loses, and the round-4 traces show how
+    // (profiles/r04_trace_pipeline_*.txt, DESIGN.md section 5 "Streams"): at 1024 envs the 2048 wavefronts of a sim batch
+    // take every wave slot of the GPU (2 per SIMD) for the whole batch, and the tick launched beside it "runs" 338-526 us
+    // instead of 58 waiting for a slot; at 512 envs on half the CUs the two wavefronts of an env share SIMDs with their
+    // neighbours', the sim becomes the slower stream (up to 95 us per step) and the tick stream stalls on the snapshot ring.
 #define TSIDB_LAUNCH_SIM(NW, MULTI)                                                                                                    \
     hipLaunchKernelGGL((k_sim<T, NW, MULTI>), dim3(h->num_envs), dim3(WAVE * NW), h->lds_pad, s, (const DevModel<T> *)h->d_model, h->num_envs, B, ring, \
                        (T *)qpos, (T *)qvel, (T *)qacc_ws, (const T *)h->env_params, (const T *)h->terrain, (const T *)motor_tau,     \
@@ -1020,6 +1036,7 @@ static void launch_reset(tsidb_ctx *h, const int32_t *env_ids, int n_ids, void *
                          const void *done_rows, int rows_ld, void *frames, hipStream_t s) {
   const int grid = env_ids ? n_ids : h->num_envs;
   if (grid <= 0) return;
+  h->note_stream(s);
   hipLaunchKernelGGL(k_reset<T>, dim3(grid), dim3(WAVE), 0, s, (const DevModel<T> *)h->d_model, h->num_envs, env_ids, n_ids, (T *)q,
                      (T *)v, (T *)qpos, (T *)qvel, (T *)qacc_ws, (T *)h->com_ref, (T *)h->posture_ref, (T *)h->foot_ref,
                      (T *)h->contact_ref, (uint8_t *)h->contact_active, (T *)h->cop_frames, (T *)h->cop_ref, (const T *)done_rows,
@@ -1095,9 +1112,11 @@ int tsidb_set_params(tsidb_handle h, const double *params, int n_params) {
   GUARD_BEGIN
   if (!params || n_params != P_COUNT) throw std::string("params must hold TSIDB_P_COUNT doubles");
   h->params.assign(params, params + n_params);
-  // kernels in flight on any stream (the pipelined sim stage runs on a non-blocking side stream) read the model
-  // constants: wait for all of them before the constants are replaced.  A rare call (RobotConfig edits).
-  HIP_OK(hipDeviceSynchronize());
+  // kernels in flight (the pipelined sim stage runs on a side stream) read the model constants: wait for the streams THIS
+  // handle has launched on before the constants are replaced - not for the whole device (other handles, the caller's own
+  // work and collectives keep running).  A stream the caller has destroyed since has nothing in flight: its error is dropped.
+  for (hipStream_t st : h->used_streams)
+    if (hipStreamSynchronize(st) != hipSuccess) (void)hipGetLastError();
   if (h->dtype == TSIDB_F64) upload_model<double>(h); else upload_model<float>(h);
   GUARD_END
 }
@@ -1159,7 +1178,11 @@ int tsidb_stream_create(tsidb_handle h, int role, void **stream) {
 
 int tsidb_stream_destroy(tsidb_handle h, void *stream) {
   GUARD_BEGIN
-  if (stream) HIP_OK(hipStreamDestroy((hipStream_t)stream));
+  if (stream) {
+    for (size_t i = 0; i < h->used_streams.size(); i++)
+      if (h->used_streams[i] == (hipStream_t)stream) { h->used_streams.erase(h->used_streams.begin() + i); break; }
+    HIP_OK(hipStreamDestroy((hipStream_t)stream)); // (hipStreamDestroy lets the stream's pending work finish)
+  }
   GUARD_END
 }
 
@@ -1210,6 +1233,18 @@ int tsidb_walk_plan(tsidb_handle h, const int32_t *env_ids, int n_ids, const voi
   if (!(plan_params[0] > 0) || !(plan_params[3] > 0) || !(plan_params[5] > 0) || !(plan_params[4] > 0 && plan_params[4] < 1))
     throw std::string("tsidb_walk_plan: step_length, step_duration, t_start must be positive and rise_ratio inside (0, 1)");
   if (done_rows && rows_ld < NROW) throw std::string("tsidb_walk_plan: the done mask needs rows of at least TSIDB_NROW values");
+  // one thread per env walks its path vertex by vertex: every loop bound that comes from a parameter is checked here
+  for (int i = 0; i < TSIDB_PLAN_NPARAMS; i++)
+    if (!std::isfinite(plan_params[i])) throw std::string("tsidb_walk_plan: non-finite plan parameter");
+  if (!(plan_params[1] > 0) || !(plan_params[2] >= 0) || !(plan_params[6] >= 0))
+    throw std::string("tsidb_walk_plan: step_width must be positive, step_height and com_drop non-negative");
+  if (plan_params[8] != 0 && !(plan_params[8] >= plan_params[0] / 1000))
+    throw std::string("tsidb_walk_plan: resample_ds must be 0 (vertices as given) or at least step_length / 1000");
+  if (!path) {
+    if (!(plan_params[12] <= 65536)) throw std::string("tsidb_walk_plan: the unicycle path may have at most 65536 vertices");
+    if (!scale && !(plan_params[13] > 0 && plan_params[14] >= plan_params[13])) throw std::string("tsidb_walk_plan: scale range must satisfy 0 < lo <= hi");
+    if (!(plan_params[11] > 0)) throw std::string("tsidb_walk_plan: the unicycle path's time step must be positive");
+  } else if (P > 65536) throw std::string("tsidb_walk_plan: an explicit path may have at most 65536 vertices per env");
   const int cnt = env_ids ? n_ids : h->num_envs;
   if (cnt <= 0) return 0;
   PlanParams PP;
@@ -1318,6 +1353,7 @@ int tsidb_rbd_terms(tsidb_handle h, const void *q, const void *v, void *M, void 
   GUARD_BEGIN
   if (!q || !v || !M || !hbias || !Jcom || !Jf || !oMf || !com) throw std::string("tsidb_rbd_terms: null buffer");
   hipStream_t s = (hipStream_t)stream;
+  h->note_stream(s);
   if (h->dtype == TSIDB_F64)
     hipLaunchKernelGGL(k_rbd<double>, dim3(h->num_envs), dim3(WAVE), 0, s, (const DevModel<double> *)h->d_model, h->num_envs,
                        (const double *)q, (const double *)v, (double *)M, (double *)hbias, (double *)Jcom, (double *)Jf,

@@ -117,8 +117,11 @@ class WalkController:
     def __del__(self):
         try:
             if self._h:
-                for _, hs in getattr(self, "_streams", {}).values():
-                    if hs is not None:
+                import sys
+                for ext, hs in getattr(self, "_streams", {}).values():
+                    # a caller (or a captured graph's keep list) may still hold the ExternalStream wrapper of a library
+                    # stream: then the HIP stream is left alive (a leaked stream is harmless, a dangling one is not)
+                    if hs is not None and sys.getrefcount(ext) <= 3:
                         self._L.tsidb_stream_destroy(self._h, hs)
                 self._streams = {}
                 self._L.tsidb_destroy(self._h)
@@ -359,12 +362,27 @@ class WalkController:
                     st[r] = (torch.cuda.ExternalStream(hs.value, device=self.device), hs)
                 else:
                     st[r] = (torch.cuda.Stream(device=self.device), None)   # no CU split for this batch size: torch's pool
+            ok = False
             for _ in range(6):                   # a pair that shares a hardware queue would serialise tick and sim
                 if self._streams_overlap(st[0][0], st[1][0]):
+                    ok = True
                     break
-                if st[1][1] is not None:
-                    self._L.tsidb_stream_destroy(self._h, st[1][1])
-                st[1] = (torch.cuda.Stream(device=self.device), None)
+                if st[0][1] is not None or st[1][1] is not None:
+                    # the CU-masked pair does not overlap: give up the split for BOTH roles (a tick confined to half the
+                    # CUs beside a sim that spans all of them is a silent regression) and say so
+                    import warnings
+                    warnings.warn("tsid_control_amd: the CU-masked tick / sim streams do not run concurrently on this device; "
+                                  "using ordinary streams for both (no CU split)")
+                    for r in (0, 1):
+                        if st[r][1] is not None:
+                            self._L.tsidb_stream_destroy(self._h, st[r][1])
+                        st[r] = (torch.cuda.Stream(device=self.device), None)
+                else:
+                    st[1] = (torch.cuda.Stream(device=self.device), None)
+            if not ok and not self._streams_overlap(st[0][0], st[1][0]):
+                import warnings
+                warnings.warn("tsid_control_amd: no pair of HIP streams that runs concurrently was found (they share a hardware "
+                              "queue): the pipelined step will run tick and sim one after the other")
         return st[role][0]
 
     @property

@@ -219,7 +219,7 @@ class WalkSchedule:
         self.pp = plan_params(conf, t_start, com_drop, foot_press, resample_ds, unicycle, scale_range, seed)
         self.t_start, self.dz = float(t_start), float(com_drop)
         self.z0 = float(wc.com_ref[0, 2])   # (standing CoM height: the same for every env right after a reset)
-        self.omega = float(np.sqrt(GRAVITY / (self.z0 - self.dz)))
+        self.omega = float(np.sqrt(GRAVITY / max(self.z0 - self.dz, 1e-3)))   # (k_plan's guard: such envs are flagged and stand)
         if plan:
             self.plan(wc)
         return self
