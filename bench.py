@@ -422,7 +422,7 @@ def secondary_runs(a, dev):
     out = {}
     base = dict(dtype=a.dtype, randomize=False, dephase=0.0, tau_max_scaling=None, graph=0, steps=a.secondary_steps, warmup=20,
                 preroll=600, event_every=4, no_overlap=a.no_overlap, sync_gather=False, self_collision=a.self_collision,
-                robot="v1", closed_loop=False, sim_batch=0)
+                robot="v1", closed_loop=False, sim_batch=0, device_plan=False)
     cases = [
         ("cfg2_stand_1024", dict(workload="stand", steps=max(a.secondary_steps, 400), warmup=200), 1024),
         ("cfg2_stand_4096", dict(workload="stand", steps=max(a.secondary_steps, 400), warmup=200), 4096),
@@ -435,6 +435,10 @@ def secondary_runs(a, dev):
         # the per-GPU share of the 4096 walkers at 8 GPUs (strong split): a step is one wavefront's latency.  (Replaying the
         # steps from a HIP graph - WalkController.capture_steps, a convenience API for callers that want one launch per K
         # steps - is slower than this eager pipeline, DESIGN.md section 5 "Streams", and is no longer benched: --graph K.)
+        # the headline workload with the plans built and the episodes restarted ON THE DEVICE (bench.py --device-plan): same
+        # path scales U(0.5, 1) and table capacity as the host-planned headline, same 20-step window
+        ("cfg3_walk_4096_device_plan_driver_window", dict(workload="walk", device_plan=True, steps=20, warmup=5, preroll=600, event_every=8), 4096),
+        ("cfg3_walk_4096_device_plan", dict(workload="walk", device_plan=True, steps=max(a.secondary_steps * 5, 1000), preroll=600, event_every=8), 4096),
         ("cfg3_walk_4096_closed_loop", dict(workload="walk", closed_loop=True, steps=max(a.secondary_steps, 400), preroll=600), 4096),
         ("cfg3_walk_512_eager", dict(workload="walk", steps=800), 512),
         # the per-GPU shares of the 4096 walkers at 4 and 2 GPUs (strong split)
@@ -590,6 +594,14 @@ def main():
                "f64_frac_of_vector_peak": pmc["f64_lane_flops_issued_per_env"] * n / t_s / 1e12 / VALU_PEAK_TFLOPS["f64"],
                "f64_share_of_valu_instructions": pmc["f64_share_of_valu"],
                "valu_issue_floor_ms_at_2p4GHz": 1e3 * floor_s, "valu_issue_floor_frac_of_launch": floor_s / t_s}
+    flat = {}
+    if pmc and "issue_floor_cycles_per_env" in pmc and pmc.get("wave_cycles_per_env"):
+        # two wavefronts share a SIMD; SQ_WAVE_CYCLES counts quad-cycles
+        flat["valu_issue_frac"] = 2.0 * pmc["issue_floor_cycles_per_env"] / (4.0 * pmc["wave_cycles_per_env"])
+        if pmc.get("launch_us_back_to_back_under_pmc"):
+            fr = pmc["f64_lane_flops_issued_per_env"] * 4096 / (pmc["launch_us_back_to_back_under_pmc"] * 1e-6) / 1e12 / VALU_PEAK_TFLOPS["f64"]
+            flat["f64_issued_frac_of_vector_peak"] = fr
+            flat["f64_useful_frac"] = fr * USEFUL_LANES / 64.0
     if rank == 0:
         value = world * n * args.steps / el
         out = {
@@ -616,9 +628,12 @@ def main():
                          # slots used (two wavefronts per SIMD; 4 cycles per float64 instruction, 2 per other), float64
                          # lane-flops as issued / on the 26 of 64 lanes that carry a dof, against the 78.6 TFLOP/s vector
                          # peak, share of the wavefronts' cycles spent waiting (SQ_WAIT_ANY / SQ_WAVE_CYCLES), residency
-                         "valu_issue_frac": vec["valu_issue_floor_frac_of_launch"] if vec else None,
-                         "f64_issued_frac_of_vector_peak": vec["f64_frac_of_vector_peak"] if vec else None,
-                         "f64_useful_frac": vec["f64_frac_of_vector_peak"] * USEFUL_LANES / 64.0 if vec else None,
+                         # (all four from the committed back-to-back PMC passes, profiles/pmc_traffic.json - the counters
+                         #  cannot be collected inside this run; the nested dicts below price the same counters with THIS
+                         #  run's launch time, which under overlap includes the other kernel's share of the SIMDs)
+                         "valu_issue_frac": flat.get("valu_issue_frac"),
+                         "f64_issued_frac_of_vector_peak": flat.get("f64_issued_frac_of_vector_peak"),
+                         "f64_useful_frac": flat.get("f64_useful_frac"),
                          "wait_any_frac": (pmc["wait_any_cycles_per_env"] / pmc["wave_cycles_per_env"]) if pmc and "wait_any_cycles_per_env" in pmc else None,
                          "waves_per_simd": WAVES_PER_SIMD[args.dtype],
                          "valu_issue_from_profiles": pmc, "vector_roofline_from_profiles": vec,

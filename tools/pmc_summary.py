@@ -49,13 +49,25 @@ if tj:
     out["measured_on"] = {"dtype": "f64", "envs": 4096, "workload": "walk", "self_collision": 1}
     out["source"] = ("rocprofv3 --kernel-trace --pmc passes of tools/pmc_profile.sh: bench.py --steps 100 --warmup 5 "
                      "--no-overlap, last %s dispatches of each kernel" % (last or "all"))
+    # launch durations of the same back-to-back runs (every PMC pass also carries the kernel trace)
+    dur = collections.defaultdict(list)
+    for f in sorted(glob.glob(root + "/**/*kernel_trace.csv", recursive=True)):
+        per = collections.defaultdict(list)
+        for r in csv.DictReader(open(f)):
+            k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+            if k.startswith("k_"):
+                per[k].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+        for k, v in per.items():
+            d = [x[1] for x in sorted(v)]
+            dur[k].extend(d[-last:] if last else d)
     out["valu"] = {}
     for name, kernels in (("k_tick", [k for k in acc if k.startswith("k_tick<double")]), ("k_sim", [k for k in acc if k.startswith("k_sim<double")])):
         n_env = 4096.0
         g = lambda c: sum(mean(k, c) for k in kernels)
         out["valu"][name] = {"valu_inst_per_env": g("SQ_INSTS_VALU") / n_env, "salu_inst_per_env": g("SQ_INSTS_SALU") / n_env,
                              "lds_inst_per_env": g("SQ_INSTS_LDS") / n_env, "wave_cycles_per_env": g("SQ_WAVE_CYCLES") / n_env,
-                             "wait_any_cycles_per_env": g("SQ_WAIT_ANY") / n_env}
+                             "wait_any_cycles_per_env": g("SQ_WAIT_ANY") / n_env,
+                             "launch_us_back_to_back_under_pmc": sum(sum(dur[k]) / len(dur[k]) for k in kernels if dur[k]) / 1e3}
         # instruction classes (pass p5).  float64 flops per env as ISSUED (x 64 lanes per wavefront instruction, whatever the
         # execution mask: rows of a 26-wide problem leave most lanes idle, so the useful share is lower); the issue floor
         # counts 4 cycles per double-precision instruction and 2 per other VALU instruction (two wavefronts sharing a
