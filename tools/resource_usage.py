@@ -18,7 +18,7 @@ for line in r.stderr.splitlines():
     m = re.search(r"remark:\s+Function Name: (\S+)", line)
     if m:
         nm = m.group(1)
-        d = re.match(r"_Z\d+(k_[a-z]+)I([df])((?:L[bi]\dE?)*)", nm)
+        d = re.match(r"_Z\d+(k_[a-z0-9]+)I([df])((?:L[bi]\dE?)*)", nm)
         cur = f"{d.group(1)}<{d.group(2)} {d.group(3).replace('E', ' ').strip()}>" if d else nm
         rows[cur] = {}
         continue
