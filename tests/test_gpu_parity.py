@@ -511,6 +511,28 @@ def test_shard_invariance_across_kernel_shapes(dtype):
         del part
 
 
+def test_f32_three_wavefront_sim_build_is_bit_identical():
+    """float32, 3072 envs and more, open loop: tsidb_sim runs the build of the sim kernel that is register-allocated for three
+    wavefronts per SIMD (so that the next tick runs beside it; +24 % pipelined at 4096 walkers).  Another register allocation
+    of the same arithmetic: a 512-env slice, which gets the two-wavefront build, is bit-identical."""
+    n = 3200
+    g = torch.Generator(device="cpu").manual_seed(29)
+    dq = ((torch.rand(n, 20, generator=g, dtype=torch.float64) - 0.5) * 0.08)
+    dv = torch.randn(n, 26, generator=g, dtype=torch.float64) * 0.05
+    def run(lo, hi):
+        wc = make(hi - lo, "f32")
+        wc.q[:, 7:] += dq[lo:hi].to(wc.device, wc.dtype)
+        wc.v[:] = dv[lo:hi].to(wc.device, wc.dtype)
+        for _ in range(40):
+            wc.step()
+        torch.cuda.synchronize()
+        return wc
+    full, part = run(0, n), run(1024, 1536)
+    for k in ("q", "v", "tau", "qpos", "qvel", "qacc_warmstart", "ncon", "con_pairs", "info"):
+        assert torch.equal(getattr(full, k)[1024:1536], getattr(part, k)), k
+    assert int(full.ncon.max()) >= 8 and int(full.status.abs().sum()) == 0
+
+
 def test_full_size_properties():
     """BASELINE config sizes: 4096 envs (one GPU) - size-independent properties instead of the oracle."""
     wc = make(4096)

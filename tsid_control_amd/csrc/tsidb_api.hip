@@ -221,8 +221,14 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(TSIDB_WPE)
 // (the snapshots of a batch are slots of one [K, N, NQ] / [K, N, NV] ring: two base pointers and the slot numbers packed four
 //  bits each - sixteen separate pointers were 32 SGPRs live across the whole step body)
 template <typename T> struct SimRing { const T *q, *v; unsigned long long slots; };
-template <typename T, int NW, bool MULTI>
-__global__ __launch_bounds__(WAVE * NW) __attribute__((amdgpu_waves_per_eu(TSIDB_WPE))) void k_sim(const DevModel<T> *__restrict__ mp, int n, int B, SimRing<T> ring, T *qpos, T *qvel,
+// WPE = wavefronts per SIMD the kernel is register-allocated for.  float64 needs 256 registers for its matrix rows: two.
+// float32 (10.6 KB of LDS per env: 15 workgroups per CU by LDS) has a second build for THREE (168 VGPRs, 65 spilled): alone
+// that kernel is 5 % slower, but the third slot per SIMD lets the tick kernel of the next step (146 VGPRs) run beside it -
+// pipelined 18.9 -> 23.6 M env-steps/s at 4096 walkers, 21.3 -> 24.9 M at 16 384; below ~3000 envs, where a step is one
+// wavefront's latency, and in the closed loop (tick and sim back to back) the spills cost 2-9 %, so launch_sim picks it for
+// open-loop steps of 3072 envs and more (profiles/r04_f32_wpe3.txt, r04_f32_wpe3_sizes.txt).  Same arithmetic: bit-identical.
+template <typename T, int NW, bool MULTI, int WPE = TSIDB_WPE>
+__global__ __launch_bounds__(WAVE * NW) __attribute__((amdgpu_waves_per_eu(WPE))) void k_sim(const DevModel<T> *__restrict__ mp, int n, int B, SimRing<T> ring, T *qpos, T *qvel,
                                               T *qacc_ws, const T *env_params, const T *terrain, const T *motor_tau, T *qacc, int *ncon,
                                               int *con, int *info) {
   __shared__ SimLds<T> L;
@@ -1001,7 +1007,10 @@ static void launch_sim(tsidb_ctx *h, int B, const void *q_ring, const void *v_ri
     hipLaunchKernelGGL((k_sim<T, NW, MULTI>), dim3(h->num_envs), dim3(WAVE * NW), h->lds_pad, s, (const DevModel<T> *)h->d_model, h->num_envs, B, ring, \
                        (T *)qpos, (T *)qvel, (T *)qacc_ws, (const T *)h->env_params, (const T *)h->terrain, (const T *)motor_tau,     \
                        (T *)qacc, ncon, con, info)
-    if (B == 1 && h->sim_pack && SIM_PACKABLE)
+    if (sizeof(T) == 4 && B == 1 && h->sim_waves == 1 && !h->sim_pack && !motor_tau && h->num_envs >= 3072 && !h->lds_pad)
+      hipLaunchKernelGGL((k_sim<T, 1, false, (sizeof(T) == 4 ? 3 : TSIDB_WPE)>), dim3(h->num_envs), dim3(WAVE), 0, s, (const DevModel<T> *)h->d_model, h->num_envs, B, ring,
+                         (T *)qpos, (T *)qvel, (T *)qacc_ws, (const T *)h->env_params, (const T *)h->terrain, (const T *)motor_tau, (T *)qacc, ncon, con, info);
+    else if (B == 1 && h->sim_pack && SIM_PACKABLE)
       hipLaunchKernelGGL((k_sim2<T>), dim3((h->num_envs + 1) / 2), dim3(WAVE), 0, s, (const DevModel<T> *)h->d_model, h->num_envs, ring, (T *)qpos, (T *)qvel,
                          (T *)qacc_ws, (const T *)h->env_params, (const T *)h->terrain, (const T *)motor_tau, (T *)qacc, ncon, con, info);
     else if (B > 1) { if (h->sim_waves == 2) TSIDB_LAUNCH_SIM(2, true); else TSIDB_LAUNCH_SIM(1, true); }
