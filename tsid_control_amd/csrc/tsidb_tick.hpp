@@ -952,8 +952,8 @@ __device__ __forceinline__ void tick_qp(const DevModel<T> &m, TickLds<T> &L, QpC
     }
     TSIDB_STAMP(5);
     // ---- Householder QR of B (column c on lanes c + PP g) applied to J (rows in lanes 0..n-1)
-    T R_norm = 1;
-    bool degenerate = false;
+    T R_norm = 1;    // (R_norm and the degeneracy flag are wave-uniform and live across the whole unrolled QR: pinned in
+    int degen = 0;   //  VGPRs - as SGPRs they were spilled to VGPR lanes and reloaded around every column)
     T xeq = lane < NV ? x0 : T(0);
 #pragma unroll
     for (int k = 0; k < PP; k++) {
@@ -1033,10 +1033,12 @@ __device__ __forceinline__ void tick_qp(const DevModel<T> &m, TickLds<T> &L, QpC
           }
         }
         const T ad = fabs(dkk);
-        if (ad <= Eps<T>::v * R_norm) degenerate = true;
-        if (ad > R_norm) R_norm = ad;
+        degen = ad <= Eps<T>::v * R_norm ? 1 : degen;
+        R_norm = ad > R_norm ? ad : R_norm;
+        asm volatile("" : "+v"(degen), "+v"(R_norm));
       }
     }
+    const bool degenerate = degen != 0;
     // ---- R^T t = -c (forward), x = x0 + J[:, :p] t  (the equality multipliers u = R^-1 t are not needed).
     //      R[i][c] sits on lane c + PP g(i): tg[g] is column c's running sum over the rows of group g
     T tg[G], tv[PP];
