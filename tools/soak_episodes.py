@@ -1,5 +1,6 @@
 """Soak: N walkers with device-side episodes (plan on the device, reset_done every step) for many steps; counts resets, failed
-QPs, flagged sim envs, non-finite states.   python tools/soak_episodes.py [envs] [steps] [closed]"""
+QPs (status of EVERY tick, accumulated on the device), flagged sim envs (every 50th step), non-finite states.
+    python tools/soak_episodes.py [envs] [steps] [closed]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -20,6 +21,7 @@ if closed:
 resets = torch.zeros((), dtype=torch.int64, device=wc.device)
 failed = torch.zeros((), dtype=torch.int64, device=wc.device)
 flagged = torch.zeros((), dtype=torch.int64, device=wc.device)
+failed_every = torch.zeros((), dtype=torch.int64, device=wc.device)
 t0 = time.perf_counter()
 with torch.cuda.stream(wc.tick_stream):
     for i in range(steps):
@@ -27,6 +29,7 @@ with torch.cuda.stream(wc.tick_stream):
             sched.apply(wc, wc.t); wc.step()
         else:
             wc.step_pipelined(walk=(sched, wc.t))
+        failed_every.add_((wc.status != 0).sum())   # every tick (two tiny kernels on the tick stream, no host sync)
         if i % 50 == 49:
             # an episode also ends when its plan is walked to the end: mark those envs done (t > t_start + nsteps T + 1 s)
             tl = wc.t - sched.t_offset.double()
@@ -42,5 +45,5 @@ torch.cuda.synchronize()
 el = time.perf_counter() - t0
 ok = bool(torch.isfinite(wc.q).all() and torch.isfinite(wc.qpos).all() and torch.isfinite(wc.qvel).all())
 print(f"{'closed' if closed else 'open'} loop, {n} envs x {steps} steps in {el:.1f} s ({n * steps / el / 1e6:.2f} M env-steps/s): episode resets {int(resets)}, "
-      f"failed-QP samples {int(failed)}, flagged-sim samples {int(flagged)}, states finite {ok}, episodes max {int(sched.episode.max())}, "
+      f"failed QPs over ALL ticks {int(failed_every)} (in the samples every 50th step: {int(failed)}), flagged-sim samples {int(flagged)}, states finite {ok}, episodes max {int(sched.episode.max())}, "
       f"base height min {float(wc.q[:, 2].min()):.3f}")
