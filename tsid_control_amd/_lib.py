@@ -64,6 +64,10 @@ def load(path=None):
     if not path.exists():
         raise TsidbError(f"{path} is missing: build the HIP extension first "
                          "(python -c 'import __graft_entry__ as g; g.build()'); there is no CPU path")
+    # torch first: its bundled HIP runtime must be the one this process initialises - the library is handed torch's device
+    # pointers and streams, and loaded before torch it would bind /opt/rocm's libamdhip64 instead (a second runtime in one
+    # process: hipGetDeviceCount then finds no device)
+    import torch  # noqa: F401
     L = C.CDLL(str(path))
     vp, i32p = C.c_void_p, C.c_void_p
     L.tsidb_create.argtypes = [vp, C.c_size_t, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
