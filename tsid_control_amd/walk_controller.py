@@ -118,6 +118,7 @@ class WalkController:
         try:
             if self._h:
                 import sys
+                self._pipe = None    # (its reference to the sim stream's wrapper is ours, not a caller's)
                 for ext, hs in getattr(self, "_streams", {}).values():
                     # a caller (or a captured graph's keep list) may still hold the ExternalStream wrapper of a library
                     # stream: then the HIP stream is left alive (a leaked stream is harmless, a dangling one is not)
