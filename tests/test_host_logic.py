@@ -98,3 +98,38 @@ def test_truncated_model_blob_is_rejected_on_the_host(blob):
         rc = L.tsidb_create(raw[:cut], cut, p.ctypes.data_as(ctypes.c_void_p), P_COUNT, 4, 0, 0, ctypes.byref(h))
         assert rc != 0 and b"model blob" in L.tsidb_last_error(h), cut
         L.tsidb_destroy(h)
+
+
+def test_bench_contract_and_execution_options():
+    """bench.py's command line (the driver's contract: --gpus / --steps / --warmup, defaults that finish in minutes) and the
+    execution options that must not change results: every secondary run names every attribute run_workload reads, the
+    option numbers of include/tsidb.h are the ones the facade passes, RobotConfig carries their switches."""
+    import sys
+    import importlib
+    sys.path.insert(0, str(ROOT))
+    bench = importlib.import_module("bench")
+    argv, sys.argv = sys.argv, ["bench.py"]
+    try:
+        a = bench.parse()
+        assert (a.gpus, a.steps, a.warmup, a.envs, a.dtype, a.workload) == (1, 5000, 20, 4096, "f64", "walk")
+        assert a.device_plan is False and a.no_overlap is False and a.closed_loop is False
+        sys.argv = ["bench.py", "--gpus", "1", "--steps", "20", "--warmup", "5", "--device-plan"]
+        b = bench.parse()
+        assert (b.steps, b.warmup, b.device_plan) == (20, 5, True)
+    finally:
+        sys.argv = argv
+    assert bench.TICK_WORDS == 347 and bench.SIM_WORDS == 185 and bench.HBM_PEAK_GBS == 8000.0
+    hdr = (ROOT / "include" / "tsidb.h").read_text()
+    m = re.search(r"enum \{ TSIDB_OPT_SIM_WAVES = (\d+), TSIDB_OPT_LDS_PAD = (\d+), TSIDB_OPT_CU_SPLIT = (\d+), TSIDB_OPT_SIM_PACK = (\d+) \}", hdr)
+    assert m and [int(g) for g in m.groups()] == [1, 2, 3, 4]
+    wc_src = (ROOT / "tsid_control_amd" / "walk_controller.py").read_text()
+    assert "tsidb_set_option(self._h, 1, sw)" in wc_src and "tsidb_set_option(self._h, 4, sp)" in wc_src
+    from tsid_control_amd import RobotConfig
+    assert RobotConfig.sim_pack == -1 and RobotConfig.sim_waves == 0 and RobotConfig.pipeline_sim_batch == 0
+    # the flat compute-roofline scalars come from the committed counter passes
+    import json
+    t = json.loads((ROOT / "profiles" / "pmc_traffic.json").read_text())
+    for k in ("k_tick", "k_sim"):
+        v = t["valu"][k]
+        assert 0.3 < 2.0 * v["issue_floor_cycles_per_env"] / (4.0 * v["wave_cycles_per_env"]) < 0.7
+        assert 100.0 < v["launch_us_back_to_back"] < 200.0 and 0.8 < t[k]["bytes_per_launch"] / (4096 * 8 * (347 if k == "k_tick" else 185)) < 1.4
