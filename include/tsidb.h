@@ -81,8 +81,13 @@ int tsidb_set_refs(tsidb_handle h, const void *com_ref, const void *posture_ref,
  * for up to 512 envs.
  * TSIDB_OPT_SIM_PACK: 1 = the sim kernel runs TWO envs per wavefront (32 lanes each; tsidb_sim2.hpp) where one step per launch
  * is issued (tsidb_sim, tsidb_step, tsidb_sim_batch with one snapshot); per env bit-identical to the one-env kernel.  Only for
- * robots whose bodies, dofs, geoms and contacts fit 32 lanes (the v1 robot); the library of another robot rejects the option. */
-enum { TSIDB_OPT_SIM_WAVES = 1, TSIDB_OPT_LDS_PAD = 2, TSIDB_OPT_CU_SPLIT = 3, TSIDB_OPT_SIM_PACK = 4 };
+ * robots whose bodies, dofs, geoms and contacts fit 32 lanes (the v1 robot); the library of another robot rejects the option.
+ * TSIDB_OPT_QP_FAST_EQ (default 1; float64, reference task stack): the tick first computes the equality-constrained optimum of
+ * the QP by the range-space route (a Cholesky of the 6-18 x 6-18 matrix B^T B instead of the Householder QR applied to the
+ * 26-50 x 26-50 factor) and runs the feasibility sweep there; an env with a violated inequality - or whose equality block is
+ * ill conditioned (a pivot ratio below 1e-4) - continues with the QR and the dual active-set iterations exactly as with 0.  The
+ * optimum is unique: results agree to rounding (1e-12 observed), status and iteration counts are the same. */
+enum { TSIDB_OPT_SIM_WAVES = 1, TSIDB_OPT_LDS_PAD = 2, TSIDB_OPT_CU_SPLIT = 3, TSIDB_OPT_SIM_PACK = 4, TSIDB_OPT_QP_FAST_EQ = 5 };
 int tsidb_set_option(tsidb_handle h, int option, int value);
 int tsidb_get_option(tsidb_handle h, int option, int *value); /* the EFFECTIVE setting (TSIDB_OPT_CU_SPLIT: 1 if tsidb_stream_create
                                                                 * masks its streams for this handle's batch size) */

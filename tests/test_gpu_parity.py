@@ -533,6 +533,39 @@ def test_f32_three_wavefront_sim_build_is_bit_identical():
     assert int(full.ncon.max()) >= 8 and int(full.status.abs().sum()) == 0
 
 
+def test_fast_equality_solve_agrees_with_the_qr_path(oracle):
+    """conf.qp_fast_equalities (TSIDB_OPT_QP_FAST_EQ, on by default): the tick first takes the equality-constrained optimum by
+    a Cholesky of B^T B and sweeps the inequalities there; only envs with a violated inequality go on to the QR + active set.
+    Against the same envs with the switch off (always the QR): statuses and iteration counts identical, solution to rounding -
+    standing and single support, perturbed states, envs WITH active inequalities (tight torque bounds) mixed in; and against
+    the oracle at the tolerances of the env-loop test."""
+    n = 256
+    mk = lambda fe: make(n, qp_fast_equalities=fe, tau_max_scaling=0.35)
+    a, b = mk(1), mk(0)
+    for w in (a, b):
+        perturb(w, 13, dq=0.06, dv=0.08)
+        w.contact_active[::3, 0] = 0          # a third of the envs in single support (38 variables)
+    st = mirror(a)
+    worst = 0.0
+    for i in range(12):
+        a.tick()
+        b.tick()
+        torch.cuda.synchronize()
+        assert torch.equal(a.status, b.status) and torch.equal(a.info[:, :2], b.info[:, :2]), i
+        for k in ("tau", "dv", "q", "v"):
+            worst = max(worst, float((getattr(a, k) - getattr(b, k)).abs().max()))
+        w0, w1 = wrench(a.f.cpu().numpy(), a.params), wrench(b.f.cpu().numpy(), b.params)
+        worst = max(worst, float(np.abs(w0 - w1).max()))
+        b.q.copy_(a.q); b.v.copy_(a.v)      # (same inputs every tick: the comparison is per tick)
+    assert worst < 1e-9, worst
+    assert int((a.info[:, 0] > 1).sum()) > n // 20 and int((a.info[:, 0] == 1).sum()) > n // 4   # both kinds of env were there
+    for i in range(12):
+        oracle.env_step_batch(a.params, st, nthreads=8)   # (a was ticked only: compare its TSID side)
+    # the oracle ran tick + sim; the TSID state does not depend on the sim (open loop)
+    assert np.array_equal(a.status.cpu().numpy(), st["status"])
+    assert diff(a.tau, st["tau"]) < 1e-7 and diff(a.dv, st["dv"]) < 1e-7 and diff(a.q, st["q"]) < 1e-9 and diff(a.v, st["v"]) < 1e-9
+
+
 def test_full_size_properties():
     """BASELINE config sizes: 4096 envs (one GPU) - size-independent properties instead of the oracle."""
     wc = make(4096)

@@ -120,12 +120,12 @@ def test_bench_contract_and_execution_options():
         sys.argv = argv
     assert bench.TICK_WORDS == 347 and bench.SIM_WORDS == 185 and bench.HBM_PEAK_GBS == 8000.0
     hdr = (ROOT / "include" / "tsidb.h").read_text()
-    m = re.search(r"enum \{ TSIDB_OPT_SIM_WAVES = (\d+), TSIDB_OPT_LDS_PAD = (\d+), TSIDB_OPT_CU_SPLIT = (\d+), TSIDB_OPT_SIM_PACK = (\d+) \}", hdr)
-    assert m and [int(g) for g in m.groups()] == [1, 2, 3, 4]
+    m = re.search(r"enum \{ TSIDB_OPT_SIM_WAVES = (\d+), TSIDB_OPT_LDS_PAD = (\d+), TSIDB_OPT_CU_SPLIT = (\d+), TSIDB_OPT_SIM_PACK = (\d+), TSIDB_OPT_QP_FAST_EQ = (\d+) \}", hdr)
+    assert m and [int(g) for g in m.groups()] == [1, 2, 3, 4, 5]
     wc_src = (ROOT / "tsid_control_amd" / "walk_controller.py").read_text()
-    assert "tsidb_set_option(self._h, 1, sw)" in wc_src and "tsidb_set_option(self._h, 4, sp)" in wc_src
+    assert "tsidb_set_option(self._h, 1, sw)" in wc_src and "tsidb_set_option(self._h, 4, sp)" in wc_src and "tsidb_set_option(self._h, 5, fe)" in wc_src
     from tsid_control_amd import RobotConfig
-    assert RobotConfig.sim_pack == -1 and RobotConfig.sim_waves == 0 and RobotConfig.pipeline_sim_batch == 0
+    assert RobotConfig.sim_pack == -1 and RobotConfig.qp_fast_equalities == -1 and RobotConfig.sim_waves == 0 and RobotConfig.pipeline_sim_batch == 0
     # the flat compute-roofline scalars come from the committed counter passes
     import json
     t = json.loads((ROOT / "profiles" / "pmc_traffic.json").read_text())

@@ -99,6 +99,8 @@ class RobotConfig:
                                # step latency for small batches; bit-identical), 0 = auto (2 up to 384 envs)
     self_collision = True      # sim stage collides the robot<->robot convex-hull pairs, as mj_step does (main.py:195);
     #                            False = floor contacts only (round-1 behaviour)
+    qp_fast_equalities = -1    # the tick's QP: 1 = try the equality-constrained optimum by a small Cholesky first (float64; results to
+                               # rounding, include/tsidb.h TSIDB_OPT_QP_FAST_EQ), 0 = always the QR, -1 = the library's default (1)
     sim_pack = -1              # sim kernel layout: 1 = two envs per wavefront (32 lanes each, tsidb_sim2.hpp; per env bit-identical to
                                # the one-env kernel), 0 = one env per wavefront, -1 = the library's choice for the batch size
     sim_plane_mesh = "mujoco"  # sim stage, floor <-> hull contacts (main.py:195).  "mujoco" = upstream's plane-mesh rule as far as it

@@ -150,7 +150,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(TSIDB_WPE)
                                                   const T *posture_ref, const T *foot_ref, const T *contact_ref,
                                                   const uint8_t *cact, const T *cop_frames, T *tau, T *dv, T *f,
                                                   int *status, T *obs, int obs_ld, T *frames, int *info, const T *qpos_sim,
-                                                  const T *qvel_sim, const T *cop_ref, WalkArgs<T> wa, T *q_snap, T *v_snap) {
+                                                  const T *qvel_sim, const T *cop_ref, WalkArgs<T> wa, T *q_snap, T *v_snap, int fast_eq) {
   __shared__ TickLds<T> L;
   const int lane = threadIdx.x;
   if ((int)blockIdx.x >= n) return;
@@ -195,17 +195,17 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(TSIDB_WPE)
     tsid_tick_env<T, 2, COP>(*mp, L, lane, q + E * NQ, v + E * NV, com_ref + E * 9, posture_ref + E * NA, foot_ref + E * 48,
                          contact_ref + E * 24, cact + E * 2, cop_frames ? cop_frames + E * 24 : nullptr, tau + E * NA,
                          dv + E * NV, f + E * 24, status + e, obs ? obs + E * obs_ld : nullptr, (obs && obs_ld >= NROW) ? obs + E * obs_ld + NOBS : nullptr, info ? info + E * 4 : nullptr,
-                         qpos_sim ? qpos_sim + E * NQ : nullptr, qvel_sim ? qvel_sim + E * NV : nullptr, cop_ref ? cop_ref + E * 3 : nullptr);
+                         qpos_sim ? qpos_sim + E * NQ : nullptr, qvel_sim ? qvel_sim + E * NV : nullptr, cop_ref ? cop_ref + E * 3 : nullptr, fast_eq != 0);
   } else if (ns == 1) {
     tsid_tick_env<T, 1, COP>(*mp, L, lane, q + E * NQ, v + E * NV, com_ref + E * 9, posture_ref + E * NA, foot_ref + E * 48,
                          contact_ref + E * 24, cact + E * 2, cop_frames ? cop_frames + E * 24 : nullptr, tau + E * NA,
                          dv + E * NV, f + E * 24, status + e, obs ? obs + E * obs_ld : nullptr, (obs && obs_ld >= NROW) ? obs + E * obs_ld + NOBS : nullptr, info ? info + E * 4 : nullptr,
-                         qpos_sim ? qpos_sim + E * NQ : nullptr, qvel_sim ? qvel_sim + E * NV : nullptr, cop_ref ? cop_ref + E * 3 : nullptr);
+                         qpos_sim ? qpos_sim + E * NQ : nullptr, qvel_sim ? qvel_sim + E * NV : nullptr, cop_ref ? cop_ref + E * 3 : nullptr, fast_eq != 0);
   } else {
     tsid_tick_env<T, 0, COP>(*mp, L, lane, q + E * NQ, v + E * NV, com_ref + E * 9, posture_ref + E * NA, foot_ref + E * 48,
                          contact_ref + E * 24, cact + E * 2, cop_frames ? cop_frames + E * 24 : nullptr, tau + E * NA,
                          dv + E * NV, f + E * 24, status + e, obs ? obs + E * obs_ld : nullptr, (obs && obs_ld >= NROW) ? obs + E * obs_ld + NOBS : nullptr, info ? info + E * 4 : nullptr,
-                         qpos_sim ? qpos_sim + E * NQ : nullptr, qvel_sim ? qvel_sim + E * NV : nullptr, cop_ref ? cop_ref + E * 3 : nullptr);
+                         qpos_sim ? qpos_sim + E * NQ : nullptr, qvel_sim ? qvel_sim + E * NV : nullptr, cop_ref ? cop_ref + E * 3 : nullptr, fast_eq != 0);
   }
   if (frames && lane < 24) frames[E * 24 + lane] = L.oMf[lane / 12][lane % 12];
   // a second copy of the TSID state this tick ends on (what q / v hold now): the sim stage of the pipelined step reads it
@@ -693,6 +693,7 @@ struct tsidb_ctx {
     for (hipStream_t x : used_streams) if (x == s) return;
     if (used_streams.size() < 32) used_streams.push_back(s);
   }
+  int qp_fast_eq = 1; // the tick tries the equality-constrained optimum by a PP x PP Cholesky before the QR (TSIDB_OPT_QP_FAST_EQ)
   int sim_pack = 0;  // two envs per wavefront in the sim kernel (k_sim2; one step per launch, robots that fit 32 lanes)
   unsigned lds_pad = 0; // diagnostic: unused dynamic LDS per workgroup of k_tick / k_sim (occupancy experiments)
   int cu_split = -1;    // tsidb_stream_create: tick and sim streams on disjoint halves of the CUs (-1 = up to 512 envs)
@@ -975,7 +976,7 @@ static void launch_tick(tsidb_ctx *h, void *q, void *v, void *tau, void *dv, voi
                      (T *)q, (T *)v, (const T *)h->com_ref, (const T *)h->posture_ref, (const T *)h->foot_ref,             \
                      (const T *)h->contact_ref, h->contact_active, (const T *)h->cop_frames, (T *)tau, (T *)dv, (T *)f,    \
                      status, (T *)obs, obs_ld, (T *)frames, info, (const T *)qpos_sim, (const T *)qvel_sim, (const T *)h->cop_ref, wa, \
-                     (T *)q_snap, (T *)v_snap)
+                     (T *)q_snap, (T *)v_snap, h->qp_fast_eq)
   if (h->params[P_W_COP] != 0.0) TSIDB_LAUNCH_TICK(true);
   else TSIDB_LAUNCH_TICK(false);
 #undef TSIDB_LAUNCH_TICK
@@ -1147,6 +1148,7 @@ int tsidb_set_option(tsidb_handle h, int option, int value) {
   if (option == TSIDB_OPT_SIM_WAVES && (value == 1 || value == 2)) { h->sim_waves = value; return 0; }
   if (option == TSIDB_OPT_LDS_PAD && value >= 0 && value <= 40960) { h->lds_pad = (unsigned)value; return 0; }
   if (option == TSIDB_OPT_SIM_PACK && (value == 0 || (value == 1 && SIM_PACKABLE))) { h->sim_pack = value; return 0; }
+  if (option == TSIDB_OPT_QP_FAST_EQ && (value == 0 || value == 1)) { h->qp_fast_eq = value; return 0; }
   if (option == TSIDB_OPT_CU_SPLIT && value >= -1 && value <= 1) { h->cu_split = value; return 0; }
   h->err = "tsidb_set_option: unknown option or value";
   return 1;
@@ -1158,6 +1160,7 @@ int tsidb_get_option(tsidb_handle h, int option, int *value) {
   if (option == TSIDB_OPT_SIM_WAVES) { *value = h->sim_waves; return 0; }
   if (option == TSIDB_OPT_LDS_PAD) { *value = (int)h->lds_pad; return 0; }
   if (option == TSIDB_OPT_SIM_PACK) { *value = h->sim_pack; return 0; }
+  if (option == TSIDB_OPT_QP_FAST_EQ) { *value = h->qp_fast_eq; return 0; }
   if (option == TSIDB_OPT_CU_SPLIT) { *value = (h->cu_split == 1 || (h->cu_split < 0 && h->num_envs <= 512)) ? 1 : 0; return 0; }
   h->err = "tsidb_get_option: unknown option";
   return 1;

@@ -746,7 +746,7 @@ __device__ __forceinline__ int qp_active_regs(const DevModel<T> &m, TickLds<T> &
 // register-resident rows/columns and every unrolled loop carry no padding for absent contacts.
 template <typename T, int NS, bool COP>
 __device__ __forceinline__ void tick_qp(const DevModel<T> &m, TickLds<T> &L, QpCtx<T> &c, int lane, const T (&a)[NV],
-                                        T rdv, T gi, T c1, bool spd, const T *cop_ref, int &qp_status, int &qp_iters) {
+                                        T rdv, T gi, T c1, bool spd, const T *cop_ref, int &qp_status, int &qp_iters, bool fast_eq) {
   // ORDER_PIN2(x, y): an empty volatile asm that "modifies" x and y.  The unrolled loops below use every broadcast value
   // (v_readlane -> an SGPR pair) twice, in two FMA chains; the compiler likes to run one chain for the whole loop and
   // then the other, keeping all the loop's broadcast values alive in between - ~100 SGPRs it does not have, so it spills
@@ -769,6 +769,21 @@ __device__ __forceinline__ void tick_qp(const DevModel<T> &m, TickLds<T> &L, QpC
   //  k_tick went from 0.154 to 0.174 ms on the walking workload.)
   constexpr int G = 3, GS = (NN + G - 1) / G;
   static_assert(G * PP <= WAVE, "the column groups of B must fit the wavefront");
+  // Fast equality solve (round 4, float64, reference stack): most ticks end with NO active inequality, and for those the
+  // equality-constrained optimum is all that is needed.  It is x0 + J0 z with z = -B (B^T B)^-1 c, the least-norm solution
+  // of B^T z + c = 0 - the same point the QR below reaches, by a PP x PP Cholesky instead of PP reflectors applied to the
+  // NN x NN factor J (a fifth of the tick).  Only when the feasibility sweep at that point fails does the env go on to the
+  // QR and the dual active-set iterations, exactly as before (B and J0 are untouched).  Scratch in the dead kinematics region
+  // of LDS: B's dv rows [NV][PP] at its start, B^T B packed behind them, both in front of B's force rows.
+  constexpr bool FASTEQ = sizeof(T) == 8 && !COP;
+  constexpr int NPAIR = PP * (PP + 1) / 2;
+  T *const Bl = reinterpret_cast<T *>(&L.k);
+  T *const Sl = Bl + NV * PP;
+  constexpr int FCL0 = 16; // B's force rows start this far into the active-set row buffer (they need 72 NS of its 160 entries)
+  T *const fcl = L.as.s + FCL0;
+  static_assert(FCL0 + 6 * 12 * NS <= 160, "force rows are staged in the active-set row buffer");
+  static_assert(!FASTEQ || ((NV * PP + NPAIR) * sizeof(T) <= offsetof(ActiveSetLds<T>, s) + FCL0 * sizeof(T)), "B's dv rows and B^T B must end before B's force rows");
+  static_assert(NV % 2 == 0, "the pair sums of B^T B take two rows at a time");
   const int grp = lane / PP, col = lane - grp * PP;
   const bool bl = lane < G * PP; // this lane holds a part of column `col`
   T jr[NN], bs[GS];
@@ -821,6 +836,12 @@ __device__ __forceinline__ void tick_qp(const DevModel<T> &m, TickLds<T> &L, QpC
         if (isbase) ck += L.h[col - NC];
         else ck -= L.k.arhs[slot_foot<T, NS>(L, col / 6)][col % 6];
       }
+      if constexpr (FASTEQ) { // the fast equality solve below reads B row by row: rows 0..NV-1 of column `col` (group 0's copy)
+        if (bl && grp == 0) {
+#pragma unroll
+          for (int i = 0; i < NV; i++) Bl[i * PP + col] = bc[i];
+        }
+      }
       // rows of the dv block go to their group's lane
 #pragma unroll
       for (int j = 0; j < GS; j++) {
@@ -850,8 +871,6 @@ __device__ __forceinline__ void tick_qp(const DevModel<T> &m, TickLds<T> &L, QpC
       // rows NV.. of B (non-zero for the base-dynamics columns only): fc[col][e] = sum_{b <= e} Jf0[b][e] Dyn[col][NV + b],
       // 6 x 12 NS dot products spread over the wavefront and handed over through LDS (the Jacobian scratch is dead now;
       // six lanes doing it alone read the 78 constants of Jf0 as wave-uniform scalars: 156 SGPRs at once)
-      static_assert(6 * 12 * NS <= 160, "force rows are staged in the active-set row buffer");
-      T *fcl = L.as.s;
       TSIDB_SYNC1();
       for (int idx = lane; idx < 6 * 12 * NS; idx += WAVE) {
         const int cl = idx / (12 * NS), rem = idx % (12 * NS), s2 = rem / 12, e = rem % 12;
@@ -951,6 +970,162 @@ __device__ __forceinline__ void tick_qp(const DevModel<T> &m, TickLds<T> &L, QpC
       TSIDB_SYNC1(); // (the sweep below writes the row buffer)
     }
     TSIDB_STAMP(5);
+    bool fast_done = false;
+    if constexpr (FASTEQ) {
+      if (spd && fast_eq) {
+        // S = B^T B, one pair (c <= d) per lane and round: 26 dv rows from LDS, the force rows for base-dynamics pairs
+        TSIDB_SYNC1();
+        for (int pidx = lane; pidx < NPAIR; pidx += WAVE) {
+          int d = (int)((sqrt(T(8 * pidx + 1)) - T(1)) * T(0.5));
+          while ((d + 1) * (d + 2) / 2 <= pidx) d++;
+          while (d * (d + 1) / 2 > pidx) d--;
+          const int cc = pidx - d * (d + 1) / 2;
+          T s0 = 0, s1 = 0;
+#pragma unroll
+          for (int r = 0; r < NV; r += 2) {
+            s0 += Bl[r * PP + cc] * Bl[r * PP + d];
+            s1 += Bl[(r + 1) * PP + cc] * Bl[(r + 1) * PP + d];
+          }
+          if constexpr (NS > 0) {
+            if (cc >= NC) { // (d >= cc): both are base-dynamics columns
+              const T *fa = fcl + (cc - NC) * 12 * NS, *fb = fcl + (d - NC) * 12 * NS;
+#pragma unroll
+              for (int e = 0; e < 12 * NS; e += 2) { s0 += fa[e] * fb[e]; s1 += fa[e + 1] * fb[e + 1]; }
+            }
+          }
+          Sl[pidx] = s0 + s1;
+        }
+        TSIDB_SYNC1();
+        // lane r < PP: row r of S in registers; Cholesky S = Ls Ls^T; then forward substitutions that share Ls's broadcasts:
+        // u = Ls^-1 c and column `lane` of Ls^-1 (as for J0 above), so that lambda = Ls^-T u needs no transposed access
+        T sr[PP];
+#pragma unroll
+        for (int j = 0; j < PP; j++) {
+          const int rr = lane < PP ? lane : 0, hi = rr > j ? rr : j, lo = rr > j ? j : rr;
+          sr[j] = lane < PP ? Sl[hi * (hi + 1) / 2 + lo] : T(0);
+        }
+        // Conditioning guard.  B^T B squares B's condition number; what is lost is governed by rho_k = Ls[k][k]^2 / S[k][k],
+        // the share of column k of B that is NOT in the span of the columns before it (scale free).  The v1 robot's
+        // equality blocks have rho >= 2e-3 (error 1e-12 against the QR); the v0 robot's two rigid 6-D contacts on five-joint
+        // legs are nearly dependent (DESIGN.md section 4 "Second robot") and lose seven digits here: below 1e-4 the env
+        // takes the QR path, which does not square anything.
+        int bad = 0;
+        T srd = 0; // lane k: 1 / Ls[k][k]
+        T sd0 = 0; // lane k: S[k][k]
+#pragma unroll
+        for (int k = 0; k < PP; k++) sd0 = ln == k ? sr[k] : sd0;
+#pragma unroll
+        for (int k = 0; k < PP; k++) {
+          const T skk = rdlane(sr[k], k);
+          bad = skk > T(1e-4) * rdlane(sd0, k) ? bad : 1;
+          const T rk = rsqrt_t(skk > 0 ? skk : T(1));
+          if (ln == k) srd = rk;
+          const T lik = ln == k ? skk * rk : sr[k] * rk;
+          sr[k] = lik;
+          T lk = lik; // (broadcasts four at a time, read ahead of their FMAs and pinned there: see the Cholesky of H_dv)
+#pragma unroll
+          for (int j0 = k + 1; j0 < PP; j0 += 4) {
+            const bool p1 = j0 + 1 < PP, p2 = j0 + 2 < PP, p3 = j0 + 3 < PP;
+            const T u0 = rdlane(lk, j0), u1 = p1 ? rdlane(lk, p1 ? j0 + 1 : 0) : T(0), u2 = p2 ? rdlane(lk, p2 ? j0 + 2 : 0) : T(0),
+                    u3 = p3 ? rdlane(lk, p3 ? j0 + 3 : 0) : T(0);
+            if (j0 > k + 1) asm volatile("" : "+v"(lk), "+v"(sr[j0 - 1]) : "s"(u0), "s"(u1), "s"(u2), "s"(u3));
+            else asm volatile("" : "+v"(lk) : "s"(u0), "s"(u1), "s"(u2), "s"(u3));
+            sr[j0] -= lk * u0;
+            if (p1) sr[j0 + 1] -= lk * u1;
+            if (p2) sr[j0 + 2] -= lk * u2;
+            if (p3) sr[j0 + 3] -= lk * u3;
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < PP; k++) asm volatile("" : "+v"(sr[k]));
+        asm volatile("" : "+v"(bad));
+        if (!__ballot(bad != 0)) {
+          T li[PP]; // column `lane` of Ls^-1
+          T acc = (bl && grp == 0) ? ck : T(0), uv = 0;
+#pragma unroll
+          for (int i = 0; i < PP; i++) {
+            const T rdi = rdlane(srd, i);
+            T xs = ln == i ? T(1) : T(0), xs1 = 0;
+#pragma unroll
+            for (int k0 = 0; k0 < i; k0 += 2) { // two broadcasts READ, then their FMAs (pinned: no SGPR pile-up)
+              const bool p1 = k0 + 1 < i;
+              const T l0 = rdlane(sr[k0], i), l1 = p1 ? rdlane(sr[p1 ? k0 + 1 : 0], i) : T(0);
+              asm volatile("" : "+v"(xs), "+v"(xs1) : "s"(l0), "s"(l1));
+              xs -= l0 * li[k0];
+              if (p1) xs1 -= l1 * li[k0 + 1];
+            }
+            li[i] = (xs + xs1) * rdi;
+            const T ui = rdlane(acc, i) * rdi;
+            if (ln == i) uv = ui;
+            acc -= sr[i] * ui;
+          }
+          T lam = 0; // lane j < PP: lambda_j = sum_k (Ls^-1)[k][j] u_k
+          {
+            T lam1 = 0;
+#pragma unroll
+            for (int k = 0; k < PP; k += 2) {
+              const bool p1 = k + 1 < PP;
+              const T u0 = rdlane(uv, k), u1 = p1 ? rdlane(uv, p1 ? k + 1 : 0) : T(0);
+              asm volatile("" : "+v"(lam), "+v"(lam1) : "s"(u0), "s"(u1));
+              lam += li[k] * u0;
+              if (p1) lam1 += li[k + 1] * u1;
+            }
+            lam += lam1;
+          }
+          // z = -B lambda (lane r = row r of B), x = x0 + J0 z
+          if (lane < PP) L.x[lane] = lam;
+          TSIDB_SYNC1();
+          T z = 0;
+          if (lane < NV) {
+#pragma unroll
+            for (int cc = 0; cc < PP; cc++) z -= Bl[lane * PP + cc] * L.x[cc];
+          } else if (lane < NN) {
+            if constexpr (NS > 0) {
+#pragma unroll
+              for (int cb = 0; cb < 6; cb++) z -= fcl[cb * 12 * NS + (lane - NV)] * L.x[NC + cb];
+            }
+          }
+          T xf = lane < NV ? x0 : T(0);
+          {
+            T xf1 = 0;
+#pragma unroll
+            for (int i = 0; i < NN; i += 2) {
+              const bool p1 = i + 1 < NN;
+              const T z0 = rdlane(z, i), z1 = p1 ? rdlane(z, p1 ? i + 1 : 0) : T(0);
+              asm volatile("" : "+v"(xf), "+v"(xf1) : "s"(z0), "s"(z1));
+              xf += jr[i] * z0;
+              if (p1) xf1 += jr[i + 1] * z1;
+            }
+            xf += xf1;
+          }
+          TSIDB_SYNC1();
+          if (lane < n) L.x[lane] = xf;
+          TSIDB_SYNC1();
+          // feasibility sweep at the equality-constrained optimum
+          c.iq = p;
+          RowDesc<T> rdf[3];
+#pragma unroll
+          for (int rr = 0; rr < 3; rr++) rdf[rr] = row_desc(m, L, c, lane + WAVE * rr);
+          act_partials(L, n, lane);
+          TSIDB_SYNC1();
+          T psi = 0;
+#pragma unroll
+          for (int rr = 0; rr < 3; rr++)
+            if (lane + WAVE * rr < c.nin) {
+              const T sv = row_eval(rdf[rr], L);
+              psi += sv < 0 ? sv : T(0);
+            }
+          psi = wave_sum(psi);
+          if (fabs(psi) <= T(c.nin) * T(2.220446049250313e-16) * c1 * c2 * T(100)) {
+            fast_done = true;
+            qp_status = 0;
+            qp_iters = 1;
+          }
+          TSIDB_SYNC1();
+        }
+      }
+    }
+    if (!fast_done) {
     // ---- Householder QR of B (column c on lanes c + PP g) applied to J (rows in lanes 0..n-1)
     T R_norm = 1;    // (R_norm and the degeneracy flag are wave-uniform and live across the whole unrolled QR: pinned in
     int degen = 0;   //  VGPRs - as SGPRs they were spilled to VGPR lanes and reloaded around every column)
@@ -1086,6 +1261,7 @@ __device__ __forceinline__ void tick_qp(const DevModel<T> &m, TickLds<T> &L, QpC
     if (status < 0) status = qp_active_regs<T, NS>(m, L, c, lane, jr, xeq, rdesc, c1, c2, (int)m.params[P_MAX_ITER], iters);
     qp_status = status;
     qp_iters = iters;
+    } // (!fast_done)
   }
 }
 
@@ -1094,7 +1270,7 @@ template <typename T, int NS, bool COP>
 __device__ __forceinline__ void tsid_tick_env(const DevModel<T> &m, TickLds<T> &L, int lane, T *q, T *v, const T *com_ref,
                               const T *posture_ref, const T *foot_ref, const T *contact_ref,
                               const uint8_t *cact, const T *cop_frames, T *tau, T *dv, T *fout, int *status_out,
-                              T *obs, T *rowx, int *info, const T *qpos_sim, const T *qvel_sim, const T *cop_ref) {
+                              T *obs, T *rowx, int *info, const T *qpos_sim, const T *qvel_sim, const T *cop_ref, bool fast_eq) {
   TSIDB_STAMP(0);
   // ---- stage state.  Closed loop: the TSID state is read from the sim state each
   //      tick - quat wxyz -> xyzw, world-frame base linear velocity -> body frame, sim joint order ->
@@ -1271,7 +1447,7 @@ __device__ __forceinline__ void tsid_tick_env(const DevModel<T> &m, TickLds<T> &
 #pragma unroll
   for (int k = 0; k < NV; k++) asm volatile("" : "+v"(a[k]));
   const bool spd = notspd == 0;
-  tick_qp<T, NS, COP>(m, L, c, lane, a, rdv, gi, c1, spd, cop_ref, qp_status, qp_iters);
+  tick_qp<T, NS, COP>(m, L, c, lane, a, rdv, gi, c1, spd, cop_ref, qp_status, qp_iters, fast_eq);
   int status = qp_status, iters = qp_iters;
 
   TSIDB_STAMP(8);

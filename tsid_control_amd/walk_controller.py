@@ -94,6 +94,11 @@ class WalkController:
             sp = int(os.environ["TSIDB_SIM_PACK"])
         if sp >= 0:
             _lib.check(L, self._h, L.tsidb_set_option(self._h, 4, sp), "tsidb_set_option(sim_pack)")
+        fe = int(getattr(conf, "qp_fast_equalities", -1))   # -1 = the library's default (on)
+        if os.environ.get("TSIDB_QP_FAST_EQ"):    # diagnostic override (A/B runs)
+            fe = int(os.environ["TSIDB_QP_FAST_EQ"])
+        if fe >= 0:
+            _lib.check(L, self._h, L.tsidb_set_option(self._h, 5, fe), "tsidb_set_option(qp_fast_eq)")
         if os.environ.get("TSIDB_LDS_PAD"):       # diagnostic (occupancy measurements): unused LDS per workgroup
             _lib.check(L, self._h, L.tsidb_set_option(self._h, 2, int(os.environ["TSIDB_LDS_PAD"])), "tsidb_set_option(lds_pad)")
         self.cop_ref = z(N, 3)   # reference of the CoP force task (legacy/biped.py:79-80; conf.w_cop)
