@@ -58,6 +58,10 @@ for lo_, hi_ in ((1, 1), (2, 3), (4, 7), (8, 15), (16, 999)):
     sel = (it >= lo_) & (it <= hi_)
     if sel.any():
         print(f"  envs with {lo_}-{hi_} qp iterations: {int(sel.sum()):5d}  median total {np.median(tt[sel]):9.0f} cyc  inequality loop {np.median((b[:, 8] - b[:, 6])[sel]):9.0f}")
+fast = it == 1
+if fast.any():   # envs that ended in the fast equality solve: stamps 5, 10, 11, 12, 6 bracket its pieces
+    for nm, (s0_, s1_) in (("  fast eq: B^T B", (5, 10)), ("  fast eq: Cholesky", (10, 11)), ("  fast eq: substitutions", (11, 12)), ("  fast eq: z, x", (12, 6)), ("  fast eq: sweep", (6, 8))):
+        print(f"{nm:26s} {np.median((b[:, s1_] - b[:, s0_])[fast]):10.0f} cyc")
 for nm, k in (("  as: sweep (row values)", 10), ("  as: select+np", 11), ("  as: d = J^T np", 12), ("  as: householder+z", 13), ("  as: r, steps, add", 14)):
     print(f"{nm:26s} {np.median(b[:, k]):10.0f} cyc (sum over iterations)")
 for nm, k in (("  rbd: setup+sincos", 15), ("  rbd: depth loop", 23), ("  rbd: inertia+force", 29), ("  rbd: subtree gather", 30), ("  rbd: per-dof h,M", 31)):

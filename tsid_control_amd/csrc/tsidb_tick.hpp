@@ -976,9 +976,9 @@ __device__ __forceinline__ void tick_qp(const DevModel<T> &m, TickLds<T> &L, QpC
         // S = B^T B, one pair (c <= d) per lane and round: 26 dv rows from LDS, the force rows for base-dynamics pairs
         TSIDB_SYNC1();
         for (int pidx = lane; pidx < NPAIR; pidx += WAVE) {
-          int d = (int)((sqrt(T(8 * pidx + 1)) - T(1)) * T(0.5));
-          while ((d + 1) * (d + 2) / 2 <= pidx) d++;
-          while (d * (d + 1) / 2 > pidx) d--;
+          int d = (int)((sqrtf((float)(8 * pidx + 1)) - 1.0f) * 0.5f); // (pair index -> (c, d), d >= c; float is exact enough
+          d += (d + 1) * (d + 2) / 2 <= pidx ? 1 : 0;                   //  for < 200 pairs, one correction step either way)
+          d -= d * (d + 1) / 2 > pidx ? 1 : 0;
           const int cc = pidx - d * (d + 1) / 2;
           T s0 = 0, s1 = 0;
 #pragma unroll
@@ -996,6 +996,7 @@ __device__ __forceinline__ void tick_qp(const DevModel<T> &m, TickLds<T> &L, QpC
           Sl[pidx] = s0 + s1;
         }
         TSIDB_SYNC1();
+        TSIDB_STAMP(10);
         // lane r < PP: row r of S in registers; Cholesky S = Ls Ls^T; then forward substitutions that share Ls's broadcasts:
         // u = Ls^-1 c and column `lane` of Ls^-1 (as for J0 above), so that lambda = Ls^-T u needs no transposed access
         T sr[PP];
@@ -1039,6 +1040,7 @@ __device__ __forceinline__ void tick_qp(const DevModel<T> &m, TickLds<T> &L, QpC
 #pragma unroll
         for (int k = 0; k < PP; k++) asm volatile("" : "+v"(sr[k]));
         asm volatile("" : "+v"(bad));
+        TSIDB_STAMP(11);
         if (!__ballot(bad != 0)) {
           T li[PP]; // column `lane` of Ls^-1
           T acc = (bl && grp == 0) ? ck : T(0), uv = 0;
@@ -1072,6 +1074,7 @@ __device__ __forceinline__ void tick_qp(const DevModel<T> &m, TickLds<T> &L, QpC
             }
             lam += lam1;
           }
+          TSIDB_STAMP(12);
           // z = -B lambda (lane r = row r of B), x = x0 + J0 z
           if (lane < PP) L.x[lane] = lam;
           TSIDB_SYNC1();
@@ -1101,6 +1104,7 @@ __device__ __forceinline__ void tick_qp(const DevModel<T> &m, TickLds<T> &L, QpC
           TSIDB_SYNC1();
           if (lane < n) L.x[lane] = xf;
           TSIDB_SYNC1();
+          TSIDB_STAMP(6);
           // feasibility sweep at the equality-constrained optimum
           c.iq = p;
           RowDesc<T> rdf[3];
