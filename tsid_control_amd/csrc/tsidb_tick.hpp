@@ -970,7 +970,7 @@ __device__ __forceinline__ void tick_qp(const DevModel<T> &m, TickLds<T> &L, QpC
       TSIDB_SYNC1(); // (the sweep below writes the row buffer)
     }
     TSIDB_STAMP(5);
-    bool fast_done = false;
+    bool fast_done = false, swept = false; // swept: the fast attempt got as far as its sweep and found a violated inequality
     if constexpr (FASTEQ) {
       if (spd && fast_eq) {
         // S = B^T B, one pair (c <= d) per lane and round: 26 dv rows from LDS, the force rows for base-dynamics pairs
@@ -1125,6 +1125,7 @@ __device__ __forceinline__ void tick_qp(const DevModel<T> &m, TickLds<T> &L, QpC
             qp_status = 0;
             qp_iters = 1;
           }
+          swept = true;
           TSIDB_SYNC1();
         }
       }
@@ -1249,7 +1250,7 @@ __device__ __forceinline__ void tick_qp(const DevModel<T> &m, TickLds<T> &L, QpC
     RowDesc<T> rdesc[3];
 #pragma unroll
     for (int rr = 0; rr < 3; rr++) rdesc[rr] = row_desc(m, L, c, lane + WAVE * rr);
-    if (status < 0) {
+    if (status < 0 && !swept) { // (after a failed fast attempt the answer is known: the active-set loop's own first sweep follows)
       act_partials(L, n, lane);
       TSIDB_SYNC1();
       T psi = 0;
