@@ -74,7 +74,7 @@ int tsidb_set_refs(tsidb_handle h, const void *com_ref, const void *posture_ref,
 
 /* execution options that do not change results.  TSIDB_OPT_SIM_WAVES: wavefronts per env in the sim kernel - 1 (one wavefront
  * per env: the throughput-optimal shape once the batch fills the GPU) or 2 (collision phase on a second wavefront beside the
- * unconstrained dynamics: shorter step latency for small batches).  Default: 2 for up to 384 envs, else 1.  Bit-identical.
+ * unconstrained dynamics: shorter step latency for small batches).  Default: 2 for up to 512 envs, else 1.  Bit-identical.
  * TSIDB_OPT_LDS_PAD (diagnostic): bytes of unused dynamic LDS added to every k_tick / k_sim workgroup (0 .. 40960) - lowers the
  * number of resident workgroups per CU, for occupancy measurements; default 0.
  * TSIDB_OPT_CU_SPLIT: whether tsidb_stream_create hands out streams on disjoint halves of the CUs: 1 always, 0 never, -1 (default)

@@ -481,7 +481,7 @@ def test_shard_invariance_bitwise():
 def test_shard_invariance_across_kernel_shapes(dtype):
     """a strong split of one batch over 1 / 2 / 8 GPUs crosses the thresholds at which the library changes the
     shape of the sim kernel - one step per launch above 1024 envs, eight per launch (a separately compiled instantiation) up
-    to 1024, two wavefronts per env up to 384 - all with the DEFAULT options and the pipelined step the bench uses.  Walkers
+    to 1024, two wavefronts per env up to 512 - all with the DEFAULT options and the pipelined step the bench uses.  Walkers
     (start phase, lift-off, a touch-down: 800 ticks) on one controller of 2048 envs against 2 x 1024 and against the first and
     the last of 8 x 256: bit-identical, in float32 as well (the library is built with -ffp-contract=on: every instantiation
     rounds alike by construction)."""
@@ -505,7 +505,7 @@ def test_shard_invariance_across_kernel_shapes(dtype):
     assert int(full.status.abs().sum()) == 0 and int((full.contact_active.sum(dim=1) == 1).sum()) > n // 2   # walking, single support
     for lo, hi in ((0, 1024), (1024, 2048), (0, 256), (1792, 2048)):
         part = run(lo, hi)
-        assert part.sim_batch == 8 and opt(part, 1) == (2 if hi - lo <= 384 else 1)
+        assert part.sim_batch == 8 and opt(part, 1) == (2 if hi - lo <= 512 else 1)
         for k in ("q", "v", "tau", "dv", "f", "status", "rows", "qpos", "qvel", "qacc_warmstart", "ncon", "con_pairs", "contact_active"):
             assert torch.equal(getattr(full, k)[lo:hi], getattr(part, k)), (dtype, lo, hi, k)
         del part
@@ -1677,7 +1677,7 @@ def test_contact_caps_are_flagged(oracle):
 
 def test_two_wavefront_sim_is_bit_identical():
     """conf.sim_waves: the small-batch shape of the sim kernel (collision phase on a second wavefront beside the
-    unconstrained dynamics; the library's default up to 384 envs, tsidb_create) against one wavefront per env - same operations on the same data,
+    unconstrained dynamics; the library's default up to 512 envs, tsidb_create) against one wavefront per env - same operations on the same data,
     bit for bit: perturbed standing, randomised floors with terrain steps, self-colliding poses"""
     n = 96
     a, b = make(n, sim_waves=1), make(n, sim_waves=2)

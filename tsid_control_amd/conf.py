@@ -96,7 +96,7 @@ class RobotConfig:
     pipeline_sim_batch = 0     # WalkController.step_pipelined(): sim stages enqueued on their stream this many at a time, as ONE
                                # launch that steps every env that many times (at most 8); 0 = auto (8 for up to 1024 envs, else 1)
     sim_waves = 0              # wavefronts per env in the sim kernel: 1, 2 (collision phase beside the unconstrained dynamics: lower
-                               # step latency for small batches; bit-identical), 0 = auto (2 up to 384 envs)
+                               # step latency for small batches; bit-identical), 0 = auto (2 up to 512 envs)
     self_collision = True      # sim stage collides the robot<->robot convex-hull pairs, as mj_step does (main.py:195);
     #                            False = floor contacts only (round-1 behaviour)
     qp_fast_equalities = -1    # the tick's QP: 1 = try the equality-constrained optimum by a small Cholesky first (float64; results to

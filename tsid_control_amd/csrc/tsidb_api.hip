@@ -998,8 +998,9 @@ static void launch_sim(tsidb_ctx *h, int B, const void *q_ring, const void *v_ri
     }
     // Two wavefronts per env (collision beside the unconstrained dynamics, bit-identical) shorten the step only while every
     // wavefront has a SIMD to itself: 2 N sim wavefronts + N of the tick running beside them on 1024 SIMDs, or 2 N on the
-    // 512 SIMDs of the sim stream's half when the streams are CU-split (<= 512 envs) - the library picks NW = 2 up to 384
-    // envs (tsidb_create; k_sim at 128 / 256 / 384 envs 5-9 % shorter).  Beyond that it loses, and the round-4 traces show how
+    // 512 SIMDs of the sim stream's half when the streams are CU-split (<= 512 envs) - the library picks NW = 2 up to 512
+    // envs (tsidb_create; k_sim 5-9 % shorter; at 448 / 512 envs it pays since round 4's shorter tick made the sim the longer
+    // stream there: 7.8 -> 8.0 M env-steps/s).  Beyond that it loses, and the round-4 traces show how
     // (profiles/r04_trace_pipeline_*.txt, DESIGN.md section 5 "Streams"): at 1024 envs the 2048 wavefronts of a sim batch
     // take every wave slot of the GPU (2 per SIMD) for the whole batch, and the tick launched beside it "runs" 338-526 us
     // instead of 58 waiting for a slot; at 512 envs on half the CUs the two wavefronts of an env share SIMDs with their
@@ -1068,7 +1069,7 @@ int tsidb_create(const void *model_blob, size_t nbytes, const double *params, in
     if (num_envs <= 0) throw std::string("num_envs must be positive");
     if (dtype != TSIDB_F64 && dtype != TSIDB_F32) throw std::string("dtype must be TSIDB_F64 or TSIDB_F32");
     h->device = device; h->dtype = dtype; h->num_envs = num_envs;
-    h->sim_waves = num_envs <= 384 ? 2 : 1; // (measured, DESIGN.md section 5 "small batches")
+    h->sim_waves = num_envs <= 512 ? 2 : 1; // (measured, DESIGN.md section 5 "Streams": up to the batch size the streams are CU-split for)
     h->blob.raw.assign((const uint8_t *)model_blob, (const uint8_t *)model_blob + nbytes);
     h->blob.validate();
     { // the blob must be for the robot this library was built for

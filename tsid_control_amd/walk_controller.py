@@ -86,7 +86,7 @@ class WalkController:
         rc = L.tsidb_set_refs(self._h, _ptr(self.com_ref), _ptr(self.posture_ref), _ptr(self.foot_ref),
                               _ptr(self.contact_ref), _ptr(self.contact_active), _ptr(self.cop_frames))
         _lib.check(L, self._h, rc, "tsidb_set_refs")
-        sw = int(getattr(conf, "sim_waves", 0))   # 0 = the library's choice (2 wavefronts per env up to 384 envs, else 1)
+        sw = int(getattr(conf, "sim_waves", 0))   # 0 = the library's choice (2 wavefronts per env up to 512 envs, else 1)
         if sw:
             _lib.check(L, self._h, L.tsidb_set_option(self._h, 1, sw), "tsidb_set_option(sim_waves)")
         sp = int(getattr(conf, "sim_pack", -1))   # -1 = the library's choice; 1 = two envs per wavefront in the sim kernel (tsidb_sim2.hpp)
